@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the Huffman decode + rasterize path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1e8 synthetic Morton-sorted points, per-batch Huffman-compressed
+(1526 batches), 1920x1080, basic {depth,colour} atomicMin raster, LOD% = 100 and frustum culling off so
+every point is decoded and rasterized. For N > 1 the scene grows to N x 1e8 points (weak
+scaling), chunks are sharded contiguously over the ranks and every step ends with the RCCL min-merge of
+the partial framebuffers.
+
+A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHUNK = 6553600
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--method", choices=["basic", "hqs"], default="basic")
+    ap.add_argument("--lod", type=int, default=100, help="LOD percent (uPointFormat); 100 = all 64 points per chain")
+    ap.add_argument("--cull", type=int, default=0)
+    ap.add_argument("--camera", choices=["overview", "closeup"], default="overview")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = automatic (bounded)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for generation / CPU baseline")
+    return ap.parse_args()
+
+
+def camera(P, name, w, h):
+    # the synthetic tile is 1 km x 1 km, heights 0..80 m (csrc/pcr_encoder.cpp Scene)
+    if name == "overview":     # camera A: whole tile in the frustum
+        return P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h)
+    return P.camera_orbit(-1.68, -0.39, 70.0, (300.0, 20.0, 45.0), w, h)   # camera B: close-up, heavy overdraw
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import pcrhpg24_amd as P
+    from pcrhpg24_amd import dist as pdist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    nthreads = args.threads or min(os.cpu_count() or 8, 16)
+
+    # ---- synthetic input: this rank's contiguous range of chunks of the global scene -------------------------
+    total_points = args.points * world
+    nchunks = -(-total_points // CHUNK)
+    c0, cn = pdist.shard_range(nchunks, world, rank)
+    first = c0 * CHUNK
+    count = min(total_points, (c0 + cn) * CHUNK) - first
+    t0 = time.time()
+    image, enc = P.synth_encode(total_points, args.seed, first, count, CHUNK, nthreads)
+    t_gen = time.time() - t0
+    hf = P.HuffmanFile(image)
+
+    # ---- load into HBM ----------------------------------------------------------------------------------------
+    ctx = P.Context(local_rank)
+    ctx.set_image_size(args.width, args.height)
+    t0 = time.time()
+    ctx.stream_begin(hf.header(), 0)
+    for b in range(hf.numBatches):
+        ctx.upload_batch(b, hf.blob(b))
+    if world > 1:
+        # shard boundary: the words that follow this shard in the global stream
+        enc_h, sep_h = hf.head_words(0)
+        head = torch.zeros(2 + 1024 + 256, dtype=torch.int32, device=dev)
+        head[0], head[1] = len(enc_h), len(sep_h)
+        head[2:2 + len(enc_h)] = torch.from_numpy(enc_h.view("int32").copy()).to(dev)
+        head[2 + 1024:2 + 1024 + len(sep_h)] = torch.from_numpy(sep_h.copy()).to(dev)
+        heads = [torch.empty_like(head) for _ in range(world)]
+        dist.all_gather(heads, head)
+        if rank + 1 < world:
+            nx = heads[rank + 1].cpu().numpy()
+            ctx.upload_tail(nx[2:2 + nx[0]].view("uint32"), nx[2 + 1024:2 + 1024 + nx[1]])
+    ctx.synchronize()
+    t_load = time.time() - t0
+
+    p = camera(P, args.camera, args.width, args.height)
+    p.lod_percent = args.lod
+    p.enable_frustum_culling = args.cull
+
+    frame = pdist.DeviceFrame(ctx, args.width, args.height, dev) if world > 1 else None
+    step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world)) if args.method == "basic" else \
+           (lambda: pdist.render_hqs_sharded(ctx, frame, p, world))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    st = ctx.stats()            # counters of the last render launch (per rank)
+    pts = torch.tensor([st["points_iterated"]], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    points_per_step = float(pts.item())
+    elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = points_per_step / (elapsed / args.steps) / 1e6
+
+    # ---- dominant kernel alone, HIP events on the stream it is launched on -------------------------------
+    kern = ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth
+    kreps = max(3, min(args.steps, 10))
+    ctx.clear(); kern(p); ctx.synchronize()
+    kms = []
+    for _ in range(kreps):
+        ctx.clear()
+        ctx.timing_begin()
+        kern(p)                 # = k_lod_prepass (1526 threads) + k_render<MODE> (1526 workgroups)
+        kms.append(ctx.timing_end())
+    kernel_ms = sum(kms) / len(kms)
+    alg_bytes = ctx.algorithmic_bytes                      # decode-pass bytes of this rank's shard (SURVEY 8d B_dec * points)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            if t.get("points") == args.points and t.get("method") == args.method and t.get("width") == args.width:
+                traffic = t.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "k_render<%s>" % ("basic" if args.method == "basic" else "hqs_depth"),
+                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": alg_bytes,
+                "bytes_per_point": round(alg_bytes / max(1, st["points_iterated"]), 4)}
+
+    # ---- CPU baseline + full-size parity check (rank 0, N == 1 only) ----------------------------------------
+    cpu_baseline, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        from tests import oracle
+        of = oracle.OracleFile(hf.buf)
+        nb = of.num_batches
+        sample = args.cpu_sample_batches or nb
+        q = p.copy()
+        t0 = time.perf_counter()
+        ofb, ost = of.render_basic(q, first=0, count=sample, nthreads=nthreads) if args.method == "basic" else \
+            of.render_hqs_depth(q, first=0, count=sample)
+        cpu_s = time.perf_counter() - t0
+        cpu_baseline = {"value": round(ost["points_iterated"] / cpu_s / 1e6, 3), "unit": "Mpoints/s",
+                        "cores": nthreads if args.method == "basic" else 1, "kind": "port",
+                        "sample": "%d of %d batches (%d points) of the same stream and camera, oracle/pcr_oracle.c, %.1f s wall"
+                                  % (sample, nb, ost["points_iterated"], cpu_s)}
+        if sample == nb:        # same inputs end to end: compare the whole framebuffer, bit for bit
+            ctx.clear(); kern(p)
+            parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb))
+
+    if rank == 0:
+        out = {
+            "metric": "Mpoints/s decoded+rasterized @%dx%d" % (args.width, args.height),
+            "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 keys / i32 deltas / f32 projection", "data": "synthetic",
+            "config": {"workload": "%d synthetic Morton-sorted points per GPU, per-batch 12-bit-clipped Huffman, %dx%d, %s, camera %s, LOD%%=%d, cull=%d"
+                                   % (args.points, args.width, args.height,
+                                      "basic atomicMin raster" if args.method == "basic" else "HQS two-pass", args.camera, args.lod, args.cull),
+                       "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
+                       "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
+                       "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
+                       "parallelism": "batch-sharded x%d + RCCL min all-reduce" % world if world > 1 else "single GPU",
+                       "generate_s": round(t_gen, 2), "load_s": round(t_load, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "parity_full_size": parity,
+        }
+        print(json.dumps(out), flush=True)
+
+    if frame is not None:
+        frame.release()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

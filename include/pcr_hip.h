@@ -1,0 +1,121 @@
+/*
+ * pcr_hip.h — C ABI of libpcr_hip.so: the MI355X (gfx950) Huffman decode + rasterize path.
+ *
+ * This is the drop-in boundary for the reference's Huffman rendering methods. Each entry point names
+ * the reference interface it replaces (paths relative to the reference checkout). The reference binds
+ * its kernels through the CUDA driver API from C++ `Method`/`Resource` plugins; a maintainer replaces
+ * those cu* calls with the functions below (INTEGRATION.md shows the adapter).
+ *
+ * Conventions: every function returns 0 on success or a negative PCR_E_* code; a human-readable
+ * message is available from pcr_last_error(ctx) (ctx == NULL: message of the last failed pcr_create
+ * on this thread). A context is externally synchronised (one caller thread at a time) and owns one
+ * HIP stream on which all of its work is enqueued in call order; calls that return data to the host
+ * synchronise that stream. No torch / C++ types cross this boundary.
+ */
+#ifndef PCR_HIP_H
+#define PCR_HIP_H
+
+#include "pcr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_OK            0
+#define PCR_E_ARG        -1   /* bad argument / call order */
+#define PCR_E_FORMAT     -2   /* malformed batch record or unsupported geometry */
+#define PCR_E_HIP        -3   /* a HIP runtime call failed */
+#define PCR_E_NOMEM      -4
+#define PCR_E_NODEVICE   -5   /* no gfx950-class device / kernels not loadable */
+
+typedef struct pcr_ctx pcr_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------------
+ * replaces: cuInit/cuDeviceGet/cuCtxCreate (src/main.cpp:58-62) and the per-method
+ * CudaProgram JIT (include/CudaProgram.h:15-70; here the code object is compiled ahead of time). */
+int         pcr_create(int device, pcr_ctx **out);
+void        pcr_destroy(pcr_ctx *ctx);
+const char *pcr_last_error(const pcr_ctx *ctx);
+/* Borrow an existing HIP stream (hipStream_t) instead of the context's own; NULL restores it. */
+int         pcr_set_stream(pcr_ctx *ctx, void *hip_stream);
+int         pcr_synchronize(pcr_ctx *ctx);
+
+/* ---- resource side: HuffmanLasData (modules/compute/HuffmanLasLoader.{h,cpp}) -------------------
+ * pcr_stream_begin  <- HuffmanLasData::load buffer creation (HuffmanLasLoader.cpp:32-77): allocates the
+ *                      stream buffers for `hdr` (+ zero pads, PCR_ENCODED_PAD_WORDS / PCR_SEPARATE_PAD_WORDS)
+ *                      and zero-fills them. batch_index_base = global index of this context's first batch
+ *                      when the file is sharded across GPUs (0 otherwise).
+ * pcr_upload_batch  <- HuffmanLasData::uploadBatch (HuffmanLasLoader.cpp:176-299): `blob` is one batch
+ *                      record (include/BatchDumpData.h:151-202), borrowed for the call. Batches must
+ *                      arrive in index order 0,1,2,... (the reference's running offsets assume it too).
+ * pcr_upload_tail   <- no reference counterpart (multi-GPU only): the first words of the batch that
+ *                      follows this shard in the global stream, so that the reference's tail over-reads
+ *                       see the same bytes as on one GPU. At most the pad sizes.
+ * pcr_stream_unload <- HuffmanLasData::unload (HuffmanLasLoader.cpp:152-174). */
+int     pcr_stream_begin(pcr_ctx *ctx, const pcr_file_header *hdr, int64_t batch_index_base);
+int     pcr_upload_batch(pcr_ctx *ctx, int64_t batch_index, const void *blob, size_t n);
+int     pcr_upload_tail(pcr_ctx *ctx, const uint32_t *encoded_words, size_t n_encoded,
+                        const int32_t *separate_words, size_t n_separate);
+int     pcr_stream_unload(pcr_ctx *ctx);
+int64_t pcr_batches_loaded(const pcr_ctx *ctx);   /* HuffmanLasData::numBatchesLoaded */
+int64_t pcr_points_loaded(const pcr_ctx *ctx);    /* HuffmanLasData::numPointsLoaded  */
+
+/* ---- method side: HuffmanMemIter / HuffmanHQS ---------------------------------------------------
+ * pcr_set_image_size <- cuMemAlloc(&fb, 8*2048*2048) (+RG, BA) in the method constructors
+ *                       (modules/huffman_hqs/huffman_hqs.h:52-54); sized by resolution here
+ *                       (pcr_fb_elems(w,h) u64 each) and cleared.
+ * pcr_clear          <- the CLEAR block (huffman_hqs.h:266-270): fb <- all ones, RG/BA <- 0.
+ * pcr_render_basic   <- cuLaunchKernel(renderProg) of HuffmanMemIter::render
+ *                       (modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h:185-195; kernel render.cu:315-540).
+ * pcr_render_hqs_depth / pcr_render_hqs_color
+ *                    <- the two launches of HuffmanHQS::render (huffman_hqs.h:191-213;
+ *                       kernels huffman_hqs/depth.cu:166-397, huffman_hqs/render.cu:328-562).
+ * pcr_resolve_basic / pcr_resolve_hqs
+ *                    <- the RESOLVE blocks (huffman_mem_iter_cuda.h:226-247, huffman_hqs.h:240-263;
+ *                       kernels resolve.cu:149-191, huffman_hqs/resolve.cu:2-47). Output is a device
+ *                       RGBA8 buffer (no GL surface), read back with pcr_read_rgba.
+ * All render/resolve calls only enqueue work. */
+int pcr_set_image_size(pcr_ctx *ctx, int width, int height);
+int pcr_clear(pcr_ctx *ctx);
+int pcr_render_basic(pcr_ctx *ctx, const pcr_render_params *p);
+int pcr_render_hqs_depth(pcr_ctx *ctx, const pcr_render_params *p);
+int pcr_render_hqs_color(pcr_ctx *ctx, const pcr_render_params *p);
+int pcr_resolve_basic(pcr_ctx *ctx, const pcr_render_params *p);
+int pcr_resolve_hqs(pcr_ctx *ctx, const pcr_render_params *p);
+
+/* Counters of the most recent render call (synchronises). */
+int pcr_get_stats(pcr_ctx *ctx, pcr_render_stats *out);
+
+/* ---- readback (the reference's cuMemcpyDtoH depth dump, huffman_hqs.h:217-237, generalised) ----- */
+int pcr_read_framebuffer(pcr_ctx *ctx, uint64_t *host, size_t n_elems);          /* n_elems <= pcr_fb_elems(w,h) */
+int pcr_read_accum(pcr_ctx *ctx, uint64_t *host_rg, uint64_t *host_ba, size_t n_elems);
+int pcr_read_rgba(pcr_ctx *ctx, uint32_t *host, size_t n_pixels);                /* n_pixels <= w*h */
+
+/* ---- multi-GPU plumbing (no reference counterpart) ------------------------------------
+ * Device pointers of the context's buffers so a collective library (RCCL through torch.distributed)
+ * can reduce them in place, or externally owned buffers to render into. */
+void *pcr_device_framebuffer(pcr_ctx *ctx);
+void *pcr_device_rg(pcr_ctx *ctx);
+void *pcr_device_ba(pcr_ctx *ctx);
+int   pcr_use_external_buffers(pcr_ctx *ctx, void *dev_fb, void *dev_rg, void *dev_ba); /* NULLs: back to own */
+/* fb[i] = min(fb[i], other[i]) over pcr_fb_elems elements; rg/ba[i] += other[i] (NULL: skip). */
+int   pcr_merge_min(pcr_ctx *ctx, const void *dev_other_fb);
+int   pcr_merge_sum(pcr_ctx *ctx, const void *dev_other_rg, const void *dev_other_ba);
+/* x ^= 1<<63 on every framebuffer element: maps unsigned order to signed order so that a signed
+ * int64 MIN all-reduce (the dtype torch.distributed exposes) computes the u64 min. */
+int   pcr_flip_sign(pcr_ctx *ctx);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * HIP events on the context's stream: begin/end bracket any sequence of enqueued calls;
+ * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
+int pcr_timing_begin(pcr_ctx *ctx);
+int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
+
+/* Algorithmic HBM bytes one render_basic launch over the loaded stream must move at least once
+ * (encoded + separate + cluster + per-batch side data), for roofline accounting. */
+int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_HIP_H */

@@ -1,0 +1,605 @@
+/*
+ * pcr_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE). See pcr_oracle.h.
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fPIC -shared   (oracle/Makefile)
+ *   -ffp-contract=off : every fused multiply-add below is written out with fmaf()/fma(); nothing else fuses.
+ *   -mfma             : fmaf()/fma() compile to the hardware instruction (same bits as glibc's soft path).
+ *
+ * Numeric contract = SURVEY.md Appendix C (IEEE-strict restatement; the reference JIT-compiles with
+ * --use_fast_math, include/CudaProgram.h:35-39, whose bits are not reproducible off NVIDIA hardware).
+ * All citations are relative to the reference checkout.
+ */
+#include "pcr_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * small vector helpers (modules/huffman_mem_iter_cuda/helper_math.h: plain per-component ops)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z, w; } f4;
+
+/* helper_math.h:1266-1269 dot(float4,float4) with left-to-right FMA contraction (Appendix C.1). */
+static inline float dot4(const float *r, f4 v)
+{
+    return fmaf(r[3], v.w, fmaf(r[2], v.z, fmaf(r[1], v.y, r[0] * v.x)));
+}
+
+/* render.cu:208-211 matMul */
+static inline f4 mat_mul(const float *m, f4 v)
+{
+    f4 o = { dot4(m + 0, v), dot4(m + 4, v), dot4(m + 8, v), dot4(m + 12, v) };
+    return o;
+}
+
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ------------------------------------------------------------------------------------------------
+ * frustum cull: render.cu:218-274 (same text in huffman_hqs/depth.cu:69-125, huffman_hqs/render.cu:70-126)
+ * ---------------------------------------------------------------------------------------------- */
+static inline float t_elem(const pcr_render_params *p, int index)
+{
+    int a = index % 4, b = index / 4;           /* render.cu:228-233: rows[a] component b */
+    return p->transform[a * 4 + b];
+}
+
+static int plane_accepts(float x, float y, float z, float w, const float bmin[3], const float bmax[3])
+{
+    /* createPlane, render.cu:239-246 */
+    float nl = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+    float nx = x / nl, ny = y / nl, nz = z / nl, c = w / nl;
+    /* p-vertex, render.cu:261-264 */
+    float vx = nx > 0.0f ? bmax[0] : bmin[0];
+    float vy = ny > 0.0f ? bmax[1] : bmin[1];
+    float vz = nz > 0.0f ? bmax[2] : bmin[2];
+    /* distanceToPoint, render.cu:235-237 */
+    float d = fmaf(nz, vz, fmaf(ny, vy, nx * vx)) + c;
+    return !(d < 0.0f);
+}
+
+static int intersects_frustum(const pcr_render_params *p, const float bmin[3], const float bmax[3])
+{
+#define T(i) t_elem(p, (i))
+    /* plane order/signs: render.cu:249-256 */
+    if (!plane_accepts(T(3) - T(0), T(7) - T(4), T(11) - T(8),  T(15) - T(12), bmin, bmax)) return 0;
+    if (!plane_accepts(T(3) + T(0), T(7) + T(4), T(11) + T(8),  T(15) + T(12), bmin, bmax)) return 0;
+    if (!plane_accepts(T(3) + T(1), T(7) + T(5), T(11) + T(9),  T(15) + T(13), bmin, bmax)) return 0;
+    if (!plane_accepts(T(3) - T(1), T(7) - T(5), T(11) - T(9),  T(15) - T(13), bmin, bmax)) return 0;
+    if (!plane_accepts(T(3) - T(2), T(7) - T(6), T(11) - T(10), T(15) - T(14), bmin, bmax)) return 0;
+    if (!plane_accepts(T(3) + T(2), T(7) + T(6), T(11) + T(10), T(15) + T(14), bmin, bmax)) return 0;
+#undef T
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cull + LOD: render.cu:333-379 (mem_iter), huffman_hqs/depth.cu:186-227, huffman_hqs/render.cu:351-392
+ * ---------------------------------------------------------------------------------------------- */
+int pcr_oracle_batch_lod(const pcr_gpu_batch *b, const pcr_render_params *p, int variant,
+                         int *num_points_to_render, int *use_double)
+{
+    /* render.cu:336 — las_min narrowed to float first */
+    float lm[3] = { (float)b->las_min_x, (float)b->las_min_y, (float)b->las_min_z };
+    float bmin[3] = { b->min_x - lm[0], b->min_y - lm[1], b->min_z - lm[2] };   /* :340 */
+    float bmax[3] = { b->max_x - lm[0], b->max_y - lm[1], b->max_z - lm[2] };   /* :341 */
+
+    if (p->enable_frustum_culling && !intersects_frustum(p, bmin, bmax)) return 0; /* :342-344 */
+
+    /* :349-367 */
+    f4 ctr = { 0.5f * (bmin[0] + bmax[0]), 0.5f * (bmin[1] + bmax[1]), 0.5f * (bmin[2] + bmax[2]), 1.0f };
+    float dx = bmin[0] - bmax[0], dy = bmin[1] - bmax[1], dz = bmin[2] - bmax[2];
+    float rad = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    f4 vc = mat_mul(p->world_view, ctr);
+    f4 ve = { vc.x + rad, vc.y + 0.0f, vc.z + 0.0f, vc.w + 0.0f };
+    f4 pc = mat_mul(p->proj, vc);
+    f4 pe = mat_mul(p->proj, ve);
+    float fw = (float)p->width, fh = (float)p->height;
+    float scx = fw * (0.5f * (pc.x / pc.w + 1.0f));
+    float scy = fh * (0.5f * (pc.y / pc.w + 1.0f));
+    float sex = fw * (0.5f * (pe.x / pe.w + 1.0f));
+    float sey = fh * (0.5f * (pe.y / pe.w + 1.0f));
+    float ddx = sex - scx, ddy = sey - scy;
+    float px = sqrtf(fmaf(ddy, ddy, ddx * ddx));
+
+    *use_double = px >= 100.0f;                                         /* :370 */
+    if (variant == PCR_ORACLE_MEM_ITER) px = px / 100.0f;               /* mem_iter render.cu:372 */
+    else                                px = (float)((double)px / 100.0); /* hqs depth.cu:223, render.cu:388 */
+    float pct = (float)((double)(1.8f * px) - 0.3);                     /* :373 */
+    pct = fmaxf((float)p->lod_percent / 100.0f, fminf(pct, 1.0f));      /* :374, helper_math clamp */
+    int npr = (int)(pct * (float)p->points_per_thread);                 /* :375 */
+    if (npr > p->points_per_thread) npr = p->points_per_thread;
+    *num_points_to_render = npr;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BC1 colour: render.cu:23-65 (always 4-colour mode)
+ * ---------------------------------------------------------------------------------------------- */
+uint32_t pcr_oracle_decode_bc1(uint64_t point_index, const uint8_t *colors)
+{
+    uint64_t block = point_index / 16, local = point_index % 16;
+    const uint8_t *bp = colors + block * 8;
+    uint32_t l = bp[0] | ((uint32_t)bp[1] << 8);
+    int cr0 = (l >> 11) & 31, cg0 = (l >> 5) & 63, cb0 = l & 31;
+    int r0 = (cr0 << 3) | (cr0 >> 2), g0 = (cg0 << 2) | (cg0 >> 4), b0 = (cb0 << 3) | (cb0 >> 2);
+    uint32_t h = bp[2] | ((uint32_t)bp[3] << 8);
+    int cr1 = (h >> 11) & 31, cg1 = (h >> 5) & 63, cb1 = h & 31;
+    int r1 = (cr1 << 3) | (cr1 >> 2), g1 = (cg1 << 2) | (cg1 >> 4), b1 = (cb1 << 3) | (cb1 >> 2);
+    int word = (bp[4 + local / 4] >> (2 * (local % 4))) & 3;
+    int r, g, b;
+    switch (word) {
+    case 0:  r = r0; g = g0; b = b0; break;
+    case 1:  r = r1; g = g1; b = b1; break;
+    case 2:  r = (r0 * 2 + r1) / 3; g = (g0 * 2 + g1) / 3; b = (b0 * 2 + b1) / 3; break;
+    default: r = (r0 + r1 * 2) / 3; g = (g0 + g1 * 2) / 3; b = (b0 + b1 * 2) / 3; break;
+    }
+    return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Lane-accurate decode of one 32-lane cluster: render.cu:404-451. The GPU runs the 32 lanes in
+ * lockstep; each symbol step ends with a ballot of the lanes whose current word ran dry, and those
+ * lanes fetch consecutive stream words in ascending lane order. Reproduced including the tail
+ * over-reads.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint32_t enc_read(const pcr_oracle_stream *s, int64_t i)
+{
+    return (i >= 0 && i < s->encoded_words) ? s->encoded[i] : 0u;
+}
+static inline int32_t sep_read(const pcr_oracle_stream *s, int64_t i)
+{
+    return (i >= 0 && i < s->separate_words) ? s->separate[i] : 0;
+}
+
+typedef void (*point_sink)(void *ctx, int chain, int i, int32_t x, int32_t y, int32_t z);
+
+static void decode_cluster(const pcr_oracle_stream *s, int64_t batch, int cluster, int npr,
+                           point_sink sink, void *ctx)
+{
+    const pcr_gpu_batch *b = &s->batches[batch];
+    const int32_t *tv = s->dt_values + b->decoder_table_offset;   /* render.cu:385, 392 */
+    const int32_t *tl = s->dt_cwlen + b->decoder_table_offset;
+    const int max_cw = (int)b->max_cw_len;
+    const uint32_t mask = ((1u << max_cw) - 1u) << (32 - max_cw);  /* :386 */
+
+    int64_t enc_ptr = b->encoding_batch_offset;                    /* :404 */
+    if (cluster >= 1) enc_ptr += s->cluster_sizes[batch * 32 + cluster - 1]; /* :407-410 */
+
+    uint32_t cur[32], nxt[32];
+    int cur_bits[32];
+    int64_t sep_ptr[32];
+    int32_t prev[32][3];
+    for (int l = 0; l < 32; ++l) {
+        int tid = cluster * 32 + l;
+        sep_ptr[l] = b->separate_batch_offset;                     /* :405 */
+        if (tid != 0) sep_ptr[l] += s->separate_sizes[batch * 1024 + tid - 1]; /* :411-413 */
+        cur[l] = enc_read(s, enc_ptr + l);                         /* :416 */
+        nxt[l] = enc_read(s, enc_ptr + 32 + l);                    /* :417 */
+        cur_bits[l] = 32;                                          /* :419 */
+        const int32_t *sv = s->start_values + ((int64_t)batch * 1024 + tid) * 3; /* :421-424 */
+        prev[l][0] = sv[0]; prev[l][1] = sv[1]; prev[l][2] = sv[2];
+    }
+    int64_t already_read = 64;                                     /* :418 */
+
+    for (int i = 0; i < npr; ++i) {                                /* :428 */
+        int32_t decoded[32][3];
+        for (int j = 0; j < 3; ++j) {                              /* :430 */
+            uint32_t warp_mask = 0;
+            for (int l = 0; l < 32; ++l) {
+                uint32_t L = cur_bits[l] == 32 ? cur[l] : (cur[l] << (32 - cur_bits[l]));  /* :431 */
+                uint32_t R = cur_bits[l] == 32 ? 0u : (nxt[l] >> cur_bits[l]);             /* :432 */
+                uint32_t key = ((L | R) & mask) >> (32 - max_cw);                           /* :433 */
+                int32_t symbol = tv[key];                                                  /* :435 */
+                int cw = (signed char)tl[key];              /* :393 narrows to char, :436 */
+                decoded[l][j] = cw > 0 ? symbol : sep_read(s, sep_ptr[l]++);               /* :438 */
+                cur_bits[l] -= abs(cw);                                                    /* :439 */
+                if (cur_bits[l] <= 0) warp_mask |= 1u << l;                                /* :442-443 */
+            }
+            int offset = 0;
+            for (int l = 0; l < 32; ++l) {
+                if (warp_mask & (1u << l)) {                                               /* :444 */
+                    /* offset == popc(warp_mask & lanes below l)  (:445; shift-by-32 == 0 on CUDA) */
+                    cur[l] = nxt[l];                                                       /* :446 */
+                    nxt[l] = enc_read(s, enc_ptr + already_read + offset);                 /* :447 */
+                    cur_bits[l] += 32;                                                     /* :448 */
+                    ++offset;
+                }
+            }
+            already_read += offset;                                                        /* :450 */
+        }
+        for (int l = 0; l < 32; ++l) {
+            /* :454-456, int32 wrap-around as on the GPU */
+            int32_t x = (int32_t)((uint32_t)decoded[l][0] + (uint32_t)prev[l][0]);
+            int32_t y = (int32_t)((uint32_t)decoded[l][1] + (uint32_t)prev[l][1]);
+            int32_t z = (int32_t)((uint32_t)decoded[l][2] + (uint32_t)prev[l][2]);
+            prev[l][0] = x; prev[l][1] = y; prev[l][2] = z;        /* :463 */
+            sink(ctx, cluster * 32 + l, i, x, y, z);
+        }
+    }
+}
+
+static void sink_store(void *ctx, int chain, int i, int32_t x, int32_t y, int32_t z)
+{
+    int32_t *o = (int32_t *)ctx + ((size_t)chain * 64 + i) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+void pcr_oracle_decode_batch(const pcr_oracle_stream *s, int64_t batch, int npr, int32_t *out_xyz)
+{
+    for (int c = 0; c < 32; ++c) decode_cluster(s, batch, c, npr, sink_store, out_xyz);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * rasterize variants
+ * ---------------------------------------------------------------------------------------------- */
+enum { MODE_BASIC, MODE_HQS_DEPTH, MODE_HQS_COLOR };
+
+typedef struct {
+    const pcr_oracle_stream *s;
+    const pcr_render_params *p;
+    int mode;
+    int64_t batch;
+    int npr, use_double;
+    double scale[3], offd[3];    /* double path: render.cu:399-400 */
+    float scalef[3], offf[3];    /* float path:  render.cu:469-470 */
+    uint64_t *fb;                /* basic / hqs depth: written; hqs colour: read */
+    uint64_t *rg, *ba;
+    size_t fb_elems;
+} raster_ctx;
+
+static void sink_raster(void *vctx, int chain, int i, int32_t cx, int32_t cy, int32_t cz)
+{
+    raster_ctx *c = (raster_ctx *)vctx;
+    const pcr_render_params *p = c->p;
+    f4 pt;
+    if (c->use_double) {   /* render.cu:459-461 */
+        pt.x = (float)fma((double)cx, c->scale[0], c->offd[0]);
+        pt.y = (float)fma((double)cy, c->scale[1], c->offd[1]);
+        pt.z = (float)fma((double)cz, c->scale[2], c->offd[2]);
+    } else {               /* render.cu:529-531 */
+        pt.x = fmaf((float)cx, c->scalef[0], c->offf[0]);
+        pt.y = fmaf((float)cy, c->scalef[1], c->offf[1]);
+        pt.z = fmaf((float)cz, c->scalef[2], c->offf[2]);
+    }
+    pt.w = 1.0f;
+    /* render.cu:453: local (ctx-relative) point index — only used to address Colors */
+    uint64_t index = (uint64_t)c->batch * PCR_POINTS_PER_BATCH + (uint64_t)chain * 64 + (uint64_t)i;
+
+    /* rasterize(): render.cu:276-303 / hqs depth.cu:127-154 / hqs render.cu:274-316 */
+    f4 pos = mat_mul(p->transform, pt);
+    float nx = pos.x / pos.w, ny = pos.y / pos.w;
+    /* inside test :296. Written so that NaNs are rejected (the reference's form would index the
+     * framebuffer with an undefined pixel id: SURVEY Appendix C.2). */
+    if (!(pos.w > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f)) return;
+    float ix = fmaf(nx, 0.5f, 0.5f) * (float)p->width;    /* :283 */
+    float iy = fmaf(ny, 0.5f, 0.5f) * (float)p->height;
+    int64_t pix = (int64_t)(int)ix + (int64_t)(int)iy * p->width;   /* :284-285 */
+    if (pix < 0 || (size_t)pix >= c->fb_elems) return;
+    uint32_t depth = f32_bits(pos.w);                                /* :287 */
+
+    if (c->mode == MODE_HQS_COLOR) {
+        uint64_t old = c->fb[pix];
+        float old_depth = bits_f32((uint32_t)(old >> 32));
+        if ((double)pos.w <= (double)old_depth * 1.01) {             /* hqs render.cu:296 */
+            uint32_t rgba = pcr_oracle_decode_bc1(index, c->s->colors);
+            uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
+            c->rg[pix] += (r << 32) | g;                              /* :309-310 */
+            c->ba[pix] += (b << 32) | 1u;                             /* :311-312 */
+        }
+        return;
+    }
+
+    uint64_t key;
+    if (c->mode == MODE_BASIC) {
+        /* mem_iter writes depth<<32|colour whatever the debug flags say (:299 overwrites newPoint; the
+         * flags only change the operand of the pre-read compare). Canonical result = min over all inside
+         * points of depth<<32|colour: the reference's non-atomic pre-read filter
+         * (:297-298) only prunes candidates that cannot win, except at exact depth ties. */
+        uint64_t hi = (uint64_t)depth << 32;
+        if (hi > (c->fb[pix] | 0xFFFFFFFFull)) return;
+        key = hi | pcr_oracle_decode_bc1(index, c->s->colors);       /* :299 */
+    } else {
+        uint32_t payload = 0;                                                               /* hqs depth.cu:144 */
+        if (p->show_num_points)      payload = (uint32_t)c->npr;                            /* depth.cu:139-140 */
+        else if (p->colorize_chunks) payload = (uint32_t)(c->s->batch_index_base + c->batch); /* :141-142 blockIdx.x */
+        key = ((uint64_t)depth << 32) | payload;
+    }
+    if (key < c->fb[pix]) c->fb[pix] = key;                           /* :300 atomicMin */
+}
+
+static void render_range(const pcr_oracle_stream *s, const pcr_render_params *p, int mode,
+                         int64_t first, int64_t count, uint64_t *fb, uint64_t *rg, uint64_t *ba,
+                         pcr_render_stats *stats)
+{
+    raster_ctx c;
+    memset(&c, 0, sizeof c);
+    c.s = s; c.p = p; c.mode = mode; c.fb = fb; c.rg = rg; c.ba = ba;
+    c.fb_elems = pcr_fb_elems(p->width, p->height);
+    for (int64_t bi = first; bi < first + count; ++bi) {
+        const pcr_gpu_batch *b = &s->batches[bi];
+        int npr = 0, use_double = 0;
+        if (stats) stats->batches_total++;
+        int variant = mode == MODE_BASIC ? PCR_ORACLE_MEM_ITER : PCR_ORACLE_HQS;
+        if (!pcr_oracle_batch_lod(b, p, variant, &npr, &use_double)) {
+            if (stats) stats->batches_culled++;
+            continue;
+        }
+        if (stats) {
+            stats->points_iterated += (int64_t)PCR_WORKGROUP_SIZE * npr;
+            stats->batches_double += use_double;
+        }
+        c.batch = bi; c.npr = npr; c.use_double = use_double;
+        c.scale[0] = b->scale_x; c.scale[1] = b->scale_y; c.scale[2] = b->scale_z;
+        c.offd[0] = b->offset_x - b->las_min_x;
+        c.offd[1] = b->offset_y - b->las_min_y;
+        c.offd[2] = b->offset_z - b->las_min_z;
+        for (int k = 0; k < 3; ++k) { c.scalef[k] = (float)c.scale[k]; c.offf[k] = (float)c.offd[k]; }
+        for (int cl = 0; cl < 32; ++cl) decode_cluster(s, bi, cl, npr, sink_raster, &c);
+    }
+}
+
+void pcr_oracle_render_basic(const pcr_oracle_stream *s, const pcr_render_params *p,
+                             int64_t first, int64_t count, uint64_t *fb, pcr_render_stats *stats)
+{
+    render_range(s, p, MODE_BASIC, first, count, fb, NULL, NULL, stats);
+}
+
+void pcr_oracle_render_hqs_depth(const pcr_oracle_stream *s, const pcr_render_params *p,
+                                 int64_t first, int64_t count, uint64_t *fb, pcr_render_stats *stats)
+{
+    render_range(s, p, MODE_HQS_DEPTH, first, count, fb, NULL, NULL, stats);
+}
+
+void pcr_oracle_render_hqs_color(const pcr_oracle_stream *s, const pcr_render_params *p,
+                                 int64_t first, int64_t count, const uint64_t *fb,
+                                 uint64_t *rg, uint64_t *ba, pcr_render_stats *stats)
+{
+    render_range(s, p, MODE_HQS_COLOR, first, count, (uint64_t *)fb, rg, ba, stats);
+}
+
+/* Multi-threaded basic render for the CPU baseline: batches striped over threads,
+ * per-thread framebuffer, final min merge. */
+typedef struct {
+    const pcr_oracle_stream *s; const pcr_render_params *p;
+    int64_t first, count; int tid, nthreads; uint64_t *fb; pcr_render_stats stats;
+} mt_job;
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    for (int64_t b = j->first + j->tid; b < j->first + j->count; b += j->nthreads)
+        render_range(j->s, j->p, MODE_BASIC, b, 1, j->fb, NULL, NULL, &j->stats);
+    return NULL;
+}
+
+int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_params *p,
+                               int64_t first, int64_t count, uint64_t *fb, int nthreads,
+                               pcr_render_stats *stats)
+{
+    if (nthreads < 1) nthreads = 1;
+    size_t n = pcr_fb_elems(p->width, p->height);
+    mt_job *jobs = (mt_job *)calloc((size_t)nthreads, sizeof *jobs);
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t].s = s; jobs[t].p = p; jobs[t].first = first; jobs[t].count = count;
+        jobs[t].tid = t; jobs[t].nthreads = nthreads;
+        jobs[t].fb = t == 0 ? fb : (uint64_t *)malloc(n * 8);
+        if (!jobs[t].fb) return -1;
+        if (t) memset(jobs[t].fb, 0xFF, n * 8);
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) {
+        pthread_join(th[t], NULL);
+        if (t) {
+            for (size_t i = 0; i < n; ++i) if (jobs[t].fb[i] < fb[i]) fb[i] = jobs[t].fb[i];
+            free(jobs[t].fb);
+        }
+        if (stats) {
+            stats->batches_total += jobs[t].stats.batches_total;
+            stats->batches_culled += jobs[t].stats.batches_culled;
+            stats->points_iterated += jobs[t].stats.points_iterated;
+            stats->batches_double += jobs[t].stats.batches_double;
+        }
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * resolve: huffman_mem_iter_cuda/resolve.cu:149-191, huffman_hqs/resolve.cu:2-47
+ * ---------------------------------------------------------------------------------------------- */
+void pcr_oracle_resolve_basic(const pcr_render_params *p, const uint64_t *fb, uint32_t *rgba)
+{
+    for (int y = 0; y < p->height; ++y)
+        for (int x = 0; x < p->width; ++x) {
+            int pix = x + y * p->width;
+            uint32_t id = (uint32_t)fb[pix];
+            uint32_t color = PCR_BACKGROUND_COLOR;
+            if (id < 0xFFFFFFFFu) {
+                if (p->show_num_points) {
+                    int npr = (int)id;
+                    uint32_t shade = (uint32_t)(((double)(float)npr / 64.0) * 255.0);   /* :170 */
+                    color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+                } else if (p->colorize_chunks) {
+                    color = id * 1234567u;                                             /* :174 */
+                } else {
+                    color = id;                                                        /* :181 (BC1 mode) */
+                }
+            }
+            rgba[pix] = color;
+        }
+}
+
+void pcr_oracle_resolve_hqs(const pcr_render_params *p, const uint64_t *fb,
+                            const uint64_t *rg, const uint64_t *ba, uint32_t *rgba)
+{
+    for (int y = 0; y < p->height; ++y)
+        for (int x = 0; x < p->width; ++x) {
+            int pix = x + y * p->width;
+            uint32_t id = (uint32_t)fb[pix];
+            uint32_t color = PCR_BACKGROUND_COLOR;
+            if (id < 0xFFFFFFFFu) {
+                if (p->show_num_points) {
+                    int npr = (int)id;
+                    uint32_t shade = (uint32_t)(((double)(float)npr / 512.0) * 255.0); /* hqs resolve.cu:24 */
+                    color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+                } else if (p->colorize_chunks) {
+                    color = id * 1234567u;
+                } else {
+                    uint32_t cnt = (uint32_t)(ba[pix] & 0xFFFFFFFFull);                /* :33 */
+                    if (cnt == 0) {
+                        color = 0; /* unreachable for a consistent depth/colour pair; defined instead of dividing by 0 */
+                    } else {
+                        uint32_t r = (uint32_t)(rg[pix] >> 32) / cnt;
+                        uint32_t g = (uint32_t)(rg[pix] & 0xFFFFFFFFull) / cnt;
+                        uint32_t b = (uint32_t)(ba[pix] >> 32) / cnt;
+                        color = (b << 16) | (g << 8) | r;                              /* :37 */
+                    }
+                }
+            }
+            rgba[pix] = color;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Scalar per-chain decoder: include/huffman.h:433-477 (decompress_udtype_subarray_fast_pjn_idea)
+ * ---------------------------------------------------------------------------------------------- */
+void pcr_oracle_decode_chain(const uint32_t *words, int64_t num_words, const int32_t *separate,
+                             const int32_t *dt_values, const int32_t *dt_cwlen,
+                             int num_symbols, int32_t *out)
+{
+    const int nb = 32, max_cw = PCR_MAX_CW_LEN;
+    int sep_ptr = 0;
+    int64_t cur_ptr = 0;
+    int cur_bits = nb;
+    const uint32_t mask = ((1u << max_cw) - 1u) << (nb - max_cw);
+#define W(i) ((i) < num_words ? words[i] : 0u)   /* huffman.h:445 pushes one dummy 0 word */
+    for (int k = 0; k < num_symbols; ++k) {
+        uint32_t L = cur_bits == nb ? W(cur_ptr) : (W(cur_ptr) << (nb - cur_bits));
+        uint32_t R = cur_bits == nb ? 0u : (W(cur_ptr + 1) >> cur_bits);
+        uint32_t key = ((L | R) & mask) >> (nb - max_cw);
+        int32_t symbol = dt_values[key];
+        int len = dt_cwlen[key];
+        int cw = abs(len);
+        out[k] = len > 0 ? symbol : separate[sep_ptr++];
+        int mb = cw < cur_bits ? cw : cur_bits;     /* :464-472 */
+        cur_bits -= mb; cw -= mb;
+        if (cw < cur_bits) cur_bits -= cw;
+        else { cur_ptr += 1; cur_bits = cur_bits + nb - cw; }
+    }
+#undef W
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * .huffman parsing: HuffmanLasLoader.h:57-85 (header), BatchDumpData.h:60-149 (record),
+ * HuffmanLasLoader.cpp:176-299 (flat arrays with running offsets)
+ * ---------------------------------------------------------------------------------------------- */
+struct pcr_oracle_file {
+    pcr_oracle_stream s;
+    pcr_gpu_batch *batches;
+    int32_t *start_values, *separate, *separate_sizes, *dt_values, *dt_cwlen, *cluster_sizes;
+    uint32_t *encoded;
+    uint8_t *colors;
+};
+
+void pcr_oracle_file_free(pcr_oracle_file *f)
+{
+    if (!f) return;
+    free(f->batches); free(f->start_values); free(f->separate); free(f->separate_sizes);
+    free(f->dt_values); free(f->dt_cwlen); free(f->cluster_sizes); free(f->encoded); free(f->colors);
+    free(f);
+}
+
+const pcr_oracle_stream *pcr_oracle_file_stream(const pcr_oracle_file *f) { return &f->s; }
+
+#define FAIL(...) do { if (err) snprintf(err, errlen, __VA_ARGS__); pcr_oracle_file_free(f); return NULL; } while (0)
+
+pcr_oracle_file *pcr_oracle_file_parse(const void *bytes, size_t n, char *err, size_t errlen)
+{
+    const uint8_t *p = (const uint8_t *)bytes;
+    pcr_oracle_file *f = (pcr_oracle_file *)calloc(1, sizeof *f);
+    if (!f) return NULL;
+    if (n < sizeof(pcr_file_header)) FAIL("file shorter than its header");
+    pcr_file_header h;
+    memcpy(&h, p, sizeof h);
+    if (h.num_batches < 0 || h.num_points != h.num_batches * PCR_POINTS_PER_BATCH)
+        FAIL("header: numPoints %lld is not numBatches %lld * 65536", (long long)h.num_points, (long long)h.num_batches);
+    size_t off = sizeof h + 8 * (size_t)h.num_batches;
+    if (n < off) FAIL("file shorter than its batch size table");
+    const int64_t nB = h.num_batches;
+    int64_t enc_words = h.encoded_bytes / 4 + PCR_ENCODED_PAD_WORDS;
+    int64_t sep_words = h.separate_bytes / 4 + PCR_SEPARATE_PAD_WORDS;
+    f->batches = (pcr_gpu_batch *)calloc((size_t)nB + 1, sizeof(pcr_gpu_batch));
+    f->start_values = (int32_t *)calloc((size_t)nB * 3072 + 1, 4);
+    f->separate_sizes = (int32_t *)calloc((size_t)nB * 1024 + 1, 4);
+    f->dt_values = (int32_t *)calloc((size_t)nB * 4096 + 1, 4);
+    f->dt_cwlen = (int32_t *)calloc((size_t)nB * 4096 + 1, 4);
+    f->cluster_sizes = (int32_t *)calloc((size_t)nB * 32 + 1, 4);
+    f->encoded = (uint32_t *)calloc((size_t)enc_words, 4);
+    f->separate = (int32_t *)calloc((size_t)sep_words, 4);
+    f->colors = (uint8_t *)calloc((size_t)nB * PCR_COLOR_BYTES_PER_BATCH + 1, 1);
+    if (!f->batches || !f->start_values || !f->separate_sizes || !f->dt_values || !f->dt_cwlen ||
+        !f->cluster_sizes || !f->encoded || !f->separate || !f->colors) FAIL("out of memory");
+
+    int64_t enc_ptr = 0, sep_ptr = 0;
+    for (int64_t b = 0; b < nB; ++b) {
+        int64_t size;
+        memcpy(&size, p + sizeof h + 8 * (size_t)b, 8);
+        if (size < PCR_BATCH_FIXED_HEADER || off + (size_t)size > n) FAIL("batch %lld: record exceeds file", (long long)b);
+        const uint8_t *r = p + off;
+        int32_t hdr[5];
+        memcpy(hdr, r, 20);
+        double sc[3], of[3];
+        float bmin[3], bmax[3], lmin[3], lmax[3];
+        int32_t dt_size, num_clusters;
+        memcpy(sc, r + 20, 24); memcpy(of, r + 44, 24);
+        memcpy(bmin, r + 68, 12); memcpy(bmax, r + 80, 12);
+        memcpy(lmin, r + 92, 12); memcpy(lmax, r + 104, 12);
+        memcpy(&dt_size, r + 116, 4); memcpy(&num_clusters, r + 120, 4);
+        if (hdr[1] != PCR_POINTS_PER_BATCH || hdr[2] != PCR_WORKGROUP_SIZE || hdr[3] != PCR_POINTS_PER_THREAD ||
+            hdr[4] != PCR_CLUSTERS_PER_THREAD || dt_size != PCR_HUFFMAN_TABLE_SIZE || num_clusters != PCR_CLUSTERS_PER_BATCH)
+            FAIL("batch %lld: unsupported geometry", (long long)b);
+        size_t o = PCR_BATCH_FIXED_HEADER;
+        size_t fixed = o + 4u * (3072 + 1024 + 4096 + 4096 + 32);
+        if ((size_t)size < fixed) FAIL("batch %lld: record too short", (long long)b);
+        memcpy(f->start_values + b * 3072, r + o, 3072 * 4); o += 3072 * 4;
+        memcpy(f->separate_sizes + b * 1024, r + o, 1024 * 4); o += 1024 * 4;
+        memcpy(f->dt_values + b * 4096, r + o, 4096 * 4); o += 4096 * 4;
+        memcpy(f->dt_cwlen + b * 4096, r + o, 4096 * 4); o += 4096 * 4;
+        memcpy(f->cluster_sizes + b * 32, r + o, 32 * 4); o += 32 * 4;
+        int64_t ne = f->cluster_sizes[b * 32 + 31], ns = f->separate_sizes[b * 1024 + 1023];
+        if (ne < 0 || ns < 0 || (size_t)size != fixed + 4u * (size_t)(ne + ns) + PCR_COLOR_BYTES_PER_BATCH)
+            FAIL("batch %lld: record size mismatch", (long long)b);          /* BatchDumpData.h:148 */
+        if (enc_ptr + ne > enc_words - PCR_ENCODED_PAD_WORDS || sep_ptr + ns > sep_words - PCR_SEPARATE_PAD_WORDS)
+            FAIL("batch %lld: stream exceeds header byte counts", (long long)b);
+        memcpy(f->encoded + enc_ptr, r + o, (size_t)ne * 4); o += (size_t)ne * 4;
+        memcpy(f->separate + sep_ptr, r + o, (size_t)ns * 4); o += (size_t)ns * 4;
+        memcpy(f->colors + b * PCR_COLOR_BYTES_PER_BATCH, r + o, PCR_COLOR_BYTES_PER_BATCH);
+
+        pcr_gpu_batch *g = &f->batches[b];      /* HuffmanLasLoader.cpp:188-211 */
+        g->min_x = bmin[0]; g->min_y = bmin[1]; g->min_z = bmin[2];
+        g->max_x = bmax[0]; g->max_y = bmax[1]; g->max_z = bmax[2];
+        g->scale_x = sc[0]; g->scale_y = sc[1]; g->scale_z = sc[2];
+        g->offset_x = of[0]; g->offset_y = of[1]; g->offset_z = of[2];
+        g->las_min_x = lmin[0]; g->las_min_y = lmin[1]; g->las_min_z = lmin[2];
+        g->las_max_x = lmax[0]; g->las_max_y = lmax[1]; g->las_max_z = lmax[2];
+        g->encoding_batch_offset = enc_ptr;
+        g->separate_batch_offset = sep_ptr;
+        g->decoder_table_offset = b * 4096;
+        g->cluster_sizes_offset = b * 32;
+        g->max_cw_len = PCR_MAX_CW_LEN;        /* (long long) log2(dt_size) */
+        enc_ptr += ne; sep_ptr += ns;
+        off += (size_t)size;
+    }
+    f->s.num_batches = nB;
+    f->s.batches = f->batches; f->s.start_values = f->start_values;
+    f->s.encoded = f->encoded; f->s.encoded_words = enc_words;
+    f->s.separate = f->separate; f->s.separate_words = sep_words;
+    f->s.separate_sizes = f->separate_sizes; f->s.dt_values = f->dt_values; f->s.dt_cwlen = f->dt_cwlen;
+    f->s.cluster_sizes = f->cluster_sizes; f->s.colors = f->colors; f->s.batch_index_base = 0;
+    return f;
+}

@@ -1,0 +1,92 @@
+/*
+ * pcr_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C, lane-accurate, IEEE-strict restatement of the reference's Huffman decode + rasterize
+ * kernels. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (pcrhpg24_amd/) never links, imports or calls it.
+ *
+ * PARITY PINNING STATUS
+ *   pinned   : Huffman dictionary/table/bit-packing/per-chain decode semantics, against the
+ *              reference's own include/huffman.h compiled unmodified (oracle/_ref, tests/test_ref_pin.py);
+ *              Morton key against src/mymorton.h; BC1 decode against src/rgbcx.cpp's unpack_bc1.
+ *   UNPINNED : the kernel-level semantics (32-lane interleaved fetch order, LOD, cull, projection,
+ *              atomicMin packing, HQS). The reference holds no golden vectors for them and its CUDA
+ *              kernels cannot run here ("parity unpinned" for these: see DESIGN.md). They follow the
+ *              reference sources line by line, cited at each function below.
+ */
+#ifndef PCR_ORACLE_H
+#define PCR_ORACLE_H
+
+#include "pcr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Flat arrays exactly as the reference loader lays them out on the device
+ * (modules/compute/HuffmanLasLoader.cpp:176-299). Reads past encoded_words / separate_words
+ * are defined as 0 (the zero pad of HuffmanLasLoader.cpp:39-41, extended: SURVEY B.4). */
+typedef struct pcr_oracle_stream {
+    int64_t              num_batches;
+    const pcr_gpu_batch *batches;          /* [nB]            */
+    const int32_t       *start_values;     /* [nB*1024*3]     */
+    const uint32_t      *encoded;          /* [encoded_words] */
+    int64_t              encoded_words;
+    const int32_t       *separate;         /* [separate_words]*/
+    int64_t              separate_words;
+    const int32_t       *separate_sizes;   /* [nB*1024] inclusive, batch-local */
+    const int32_t       *dt_values;        /* [nB*4096]       */
+    const int32_t       *dt_cwlen;         /* [nB*4096]       */
+    const int32_t       *cluster_sizes;    /* [nB*32] inclusive, batch-local   */
+    const uint8_t       *colors;           /* [nB*32768] BC1  */
+    int64_t              batch_index_base; /* global index of batch 0 (colorize_chunks payload when sharded) */
+} pcr_oracle_stream;
+
+enum { PCR_ORACLE_MEM_ITER = 0, PCR_ORACLE_HQS = 1 };
+
+/* Cull + LOD decision of one batch. variant selects the `pixelSize /= 100.0f` (mem_iter) vs
+ * `/= 100.0` (hqs) expression. Returns 0 if the batch is frustum-culled, else 1. */
+int pcr_oracle_batch_lod(const pcr_gpu_batch *b, const pcr_render_params *p, int variant,
+                         int *num_points_to_render, int *use_double);
+
+/* Lane-accurate decode of one batch: writes npr points per chain as raw int32 XYZ to
+ * out_xyz[(chain*64 + i)*3 + k], i < npr. */
+void pcr_oracle_decode_batch(const pcr_oracle_stream *s, int64_t batch, int npr, int32_t *out_xyz);
+
+uint32_t pcr_oracle_decode_bc1(uint64_t point_index, const uint8_t *colors);
+
+/* huffman_mem_iter_cuda/render.cu kernel over batches [first, first+count). fb has pcr_fb_elems(w,h) u64. */
+void pcr_oracle_render_basic(const pcr_oracle_stream *s, const pcr_render_params *p,
+                             int64_t first, int64_t count, uint64_t *fb, pcr_render_stats *stats);
+/* Same, batches striped over nthreads pthreads with private framebuffers + min merge (CPU baseline). */
+int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_params *p,
+                               int64_t first, int64_t count, uint64_t *fb, int nthreads,
+                               pcr_render_stats *stats);
+/* huffman_hqs/depth.cu */
+void pcr_oracle_render_hqs_depth(const pcr_oracle_stream *s, const pcr_render_params *p,
+                                 int64_t first, int64_t count, uint64_t *fb, pcr_render_stats *stats);
+/* huffman_hqs/render.cu (reads fb, accumulates into rg/ba) */
+void pcr_oracle_render_hqs_color(const pcr_oracle_stream *s, const pcr_render_params *p,
+                                 int64_t first, int64_t count, const uint64_t *fb,
+                                 uint64_t *rg, uint64_t *ba, pcr_render_stats *stats);
+
+/* huffman_mem_iter_cuda/resolve.cu and huffman_hqs/resolve.cu; rgba has w*h u32. */
+void pcr_oracle_resolve_basic(const pcr_render_params *p, const uint64_t *fb, uint32_t *rgba);
+void pcr_oracle_resolve_hqs(const pcr_render_params *p, const uint64_t *fb,
+                            const uint64_t *rg, const uint64_t *ba, uint32_t *rgba);
+
+/* Per-chain scalar table decoder (include/huffman.h:433-477), used to pin table semantics. */
+void pcr_oracle_decode_chain(const uint32_t *words, int64_t num_words, const int32_t *separate,
+                             const int32_t *dt_values, const int32_t *dt_cwlen,
+                             int num_symbols, int32_t *out);
+
+/* --- .huffman file parsing (modules/compute/HuffmanLasLoader.{h,cpp}, include/BatchDumpData.h:60-149) --- */
+typedef struct pcr_oracle_file pcr_oracle_file; /* owns the flat arrays */
+pcr_oracle_file *pcr_oracle_file_parse(const void *bytes, size_t n, char *err, size_t errlen);
+const pcr_oracle_stream *pcr_oracle_file_stream(const pcr_oracle_file *f);
+void pcr_oracle_file_free(pcr_oracle_file *f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

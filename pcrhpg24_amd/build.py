@@ -1,0 +1,72 @@
+"""In-tree builds of the native libraries (no JIT cache, no pip): the .so files land next to this
+file so they travel to the GPU box with the repository snapshot.
+
+    libpcr_hip.so   hipcc --offload-arch=gfx950   csrc/pcr_api.hip (+ pcr_kernels.hip.h)   the product hot path
+    libpcr_host.so  g++                           csrc/pcr_encoder.cpp                     CPU encoder / generator / camera
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_LIB = os.path.join(PKG_DIR, "libpcr_hip.so")
+HOST_LIB = os.path.join(PKG_DIR, "libpcr_host.so")
+
+# -ffp-contract=off is part of the numeric contract: FMAs are spelled out in the sources.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-Wextra", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the gfx950 code object cannot be built")
+
+
+def build_hip(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, "pcr_api.hip"), os.path.join(CSRC, "pcr_kernels.hip.h"),
+            os.path.join(INCLUDE, "pcr_hip.h"), os.path.join(INCLUDE, "pcr_types.h")]
+    if force or _stale(HIP_LIB, srcs):
+        _run([_hipcc(), *HIP_FLAGS, "-I", INCLUDE, "-I", CSRC, srcs[0], "-o", HIP_LIB])
+    return HIP_LIB
+
+
+def build_host(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, "pcr_encoder.cpp"), os.path.join(INCLUDE, "pcr_encode.h"),
+            os.path.join(INCLUDE, "pcr_types.h")]
+    if force or _stale(HOST_LIB, srcs):
+        _run(["g++", *HOST_FLAGS, "-I", INCLUDE, srcs[0], "-o", HOST_LIB, "-lpthread"])
+    return HOST_LIB
+
+
+def build_all(force: bool = False) -> None:
+    build_host(force)
+    build_hip(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print(HIP_LIB)
+    print(HOST_LIB)

@@ -1,0 +1,507 @@
+// pcr_api.hip — implementation of the C ABI in include/pcr_hip.h (libpcr_hip.so, gfx950 only).
+//
+// Host-side structure follows the reference's split into a Resource (HuffmanLasData: stream buffers,
+// modules/compute/HuffmanLasLoader.cpp) and Methods (HuffmanMemIter / HuffmanHQS: framebuffers + launches,
+// modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h, modules/huffman_hqs/huffman_hqs.h), but one context
+// owns both so a foreign-language caller needs a single handle. There is no CPU fallback: every entry point
+// that needs the device fails with PCR_E_HIP / PCR_E_NODEVICE when HIP does.
+#include "pcr_hip.h"
+#include "pcr_kernels.hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pcr;
+
+struct pcr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // resource (HuffmanLasData)
+    bool stream_open = false;
+    pcr_file_header hdr{};
+    int64_t batch_index_base = 0;
+    int64_t batches_loaded = 0, points_loaded = 0;
+    int64_t enc_ptr = 0, sep_ptr = 0;           // running word offsets (HuffmanLasLoader.h:50-53)
+    int64_t enc_words = 0, sep_words = 0;       // allocation sizes in words incl. pads
+    pcr_gpu_batch *d_batches = nullptr;
+    int32_t *d_start = nullptr;
+    uint32_t *d_encoded = nullptr;
+    int32_t *d_separate = nullptr;
+    int32_t *d_sep_sizes = nullptr;
+    int32_t *d_table_values = nullptr;
+    int8_t *d_table_lens = nullptr;
+    int32_t *d_cluster_sizes = nullptr;
+    uint8_t *d_colors = nullptr;
+    uint32_t *d_lod = nullptr;
+    pcr_render_stats *d_stats = nullptr;
+    std::vector<int8_t> lens_scratch;
+
+    // method (framebuffers)
+    int width = 0, height = 0;
+    size_t fb_elems = 0;
+    uint64_t *own_fb = nullptr, *own_rg = nullptr, *own_ba = nullptr;
+    uint64_t *fb = nullptr, *rg = nullptr, *ba = nullptr;
+    uint32_t *d_rgba = nullptr;
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int set_err(pcr_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return set_err((c), PCR_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+void free_stream_buffers(pcr_ctx *c)
+{
+    dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
+    dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod);
+    c->stream_open = false; c->batches_loaded = c->points_loaded = 0;
+    c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
+}
+
+void free_frame_buffers(pcr_ctx *c)
+{
+    dfree(c->own_fb); dfree(c->own_rg); dfree(c->own_ba); dfree(c->d_rgba);
+    c->fb = c->rg = c->ba = nullptr; c->fb_elems = 0; c->width = c->height = 0;
+}
+
+template <class T> int dalloc_zero(pcr_ctx *c, T *&p, size_t count)
+{
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(c, hipMalloc((void **)&p, bytes));
+    HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    return PCR_OK;
+}
+
+int check_params(pcr_ctx *c, const pcr_render_params *p)
+{
+    if (!c) return PCR_E_ARG;
+    if (!p) return set_err(c, PCR_E_ARG, "render params are NULL");
+    if (!c->stream_open) return set_err(c, PCR_E_ARG, "no stream loaded (call pcr_stream_begin / pcr_upload_batch)");
+    if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer (call pcr_set_image_size)");
+    if (p->width != c->width || p->height != c->height)
+        return set_err(c, PCR_E_ARG, "params image size %dx%d != framebuffer %dx%d", p->width, p->height, c->width, c->height);
+    if (p->points_per_thread != PCR_POINTS_PER_THREAD)
+        return set_err(c, PCR_E_ARG, "points_per_thread must be %d", PCR_POINTS_PER_THREAD);
+    if (p->lod_percent < 0) return set_err(c, PCR_E_ARG, "lod_percent must be >= 0");
+    return PCR_OK;
+}
+
+RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
+{
+    RenderArgs a;
+    a.p = *p;
+    a.s.batches = c->d_batches; a.s.start_values = c->d_start; a.s.encoded = c->d_encoded;
+    a.s.separate = c->d_separate; a.s.separate_sizes = c->d_sep_sizes; a.s.table_values = c->d_table_values;
+    a.s.table_lens = c->d_table_lens; a.s.cluster_sizes = c->d_cluster_sizes; a.s.colors = c->d_colors;
+    a.s.encoded_words = c->enc_words; a.s.separate_words = c->sep_words;
+    a.s.num_batches = c->batches_loaded; a.s.batch_index_base = c->batch_index_base;
+    a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
+    a.lod = c->d_lod; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
+    return a;
+}
+
+template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    const int64_t nB = c->batches_loaded;            // "don't execute a workgroup until all points inside are loaded"
+    if (nB == 0) return PCR_OK;                      // huffman_hqs.h:137
+    RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
+    HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream));
+    hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int pcr_create(int device, pcr_ctx **out)
+{
+    if (!out) return set_err(nullptr, PCR_E_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return set_err(nullptr, PCR_E_NODEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return set_err(nullptr, PCR_E_ARG, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(nullptr, PCR_E_NODEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    pcr_ctx *c = new (std::nothrow) pcr_ctx();
+    if (!c) return set_err(nullptr, PCR_E_NOMEM, "out of host memory");
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
+        hipMalloc((void **)&c->d_stats, sizeof(pcr_render_stats)) != hipSuccess) {
+        pcr_destroy(c);
+        return set_err(nullptr, PCR_E_HIP, "could not create stream/events");
+    }
+    c->stream = c->own_stream;
+    (void)hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream);
+    *out = c;
+    return PCR_OK;
+}
+
+void pcr_destroy(pcr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_stream_buffers(c);
+    free_frame_buffers(c);
+    dfree(c->d_stats);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pcr_set_stream(pcr_ctx *c, void *hip_stream)
+{
+    if (!c) return PCR_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PCR_OK;
+}
+
+int pcr_synchronize(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+// ---- resource ----------------------------------------------------------------------------------
+int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_base)
+{
+    if (!c) return PCR_E_ARG;
+    if (!h) return set_err(c, PCR_E_ARG, "header is NULL");
+    if (h->num_batches <= 0 || h->num_points != h->num_batches * PCR_POINTS_PER_BATCH)
+        return set_err(c, PCR_E_FORMAT, "header: numPoints %lld != numBatches %lld * 65536", (long long)h->num_points, (long long)h->num_batches);
+    if (h->encoded_bytes < 0 || h->separate_bytes < 0 || (h->encoded_bytes & 3) || (h->separate_bytes & 3))
+        return set_err(c, PCR_E_FORMAT, "header: bad stream byte counts");
+    if (h->num_batches > 0xFFFF)
+        return set_err(c, PCR_E_FORMAT, "at most 65535 batches (4.29e9 points) per context; shard larger files");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_stream_buffers(c);
+    c->hdr = *h; c->batch_index_base = batch_index_base;
+    const size_t nB = (size_t)h->num_batches;
+    c->enc_words = h->encoded_bytes / 4 + PCR_ENCODED_PAD_WORDS;      // HuffmanLasLoader.cpp:39-41
+    c->sep_words = h->separate_bytes / 4 + PCR_SEPARATE_PAD_WORDS;
+    int rc;
+    if ((rc = dalloc_zero(c, c->d_batches, nB)) || (rc = dalloc_zero(c, c->d_start, nB * 3072)) ||
+        (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words)) || (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words)) ||
+        (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096)) ||
+        (rc = dalloc_zero(c, c->d_table_lens, nB * 4096)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32)) ||
+        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB))) {
+        free_stream_buffers(c);
+        return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream_open = true;
+    return PCR_OK;
+}
+
+int pcr_upload_batch(pcr_ctx *c, int64_t batch_index, const void *blob, size_t n)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->stream_open) return set_err(c, PCR_E_ARG, "pcr_stream_begin has not been called");
+    if (!blob) return set_err(c, PCR_E_ARG, "blob is NULL");
+    if (batch_index != c->batches_loaded)
+        return set_err(c, PCR_E_ARG, "batches must be uploaded in order: expected %lld, got %lld", (long long)c->batches_loaded, (long long)batch_index);
+    if (batch_index >= c->hdr.num_batches) return set_err(c, PCR_E_ARG, "batch index %lld beyond header", (long long)batch_index);
+    const uint8_t *r = (const uint8_t *)blob;
+    const size_t fixed = PCR_BATCH_FIXED_HEADER + 4u * (3072 + 1024 + 4096 + 4096 + 32);
+    if (n < fixed) return set_err(c, PCR_E_FORMAT, "batch %lld: record of %zu bytes is too short", (long long)batch_index, n);
+    // include/BatchDumpData.h:60-107
+    int32_t hdr[5]; std::memcpy(hdr, r, 20);
+    double sc[3], of[3]; float bmin[3], bmax[3], lmin[3], lmax[3]; int32_t dt_size, num_clusters;
+    std::memcpy(sc, r + 20, 24); std::memcpy(of, r + 44, 24);
+    std::memcpy(bmin, r + 68, 12); std::memcpy(bmax, r + 80, 12);
+    std::memcpy(lmin, r + 92, 12); std::memcpy(lmax, r + 104, 12);
+    std::memcpy(&dt_size, r + 116, 4); std::memcpy(&num_clusters, r + 120, 4);
+    if (hdr[1] != PCR_POINTS_PER_BATCH || hdr[2] != PCR_WORKGROUP_SIZE || hdr[3] != PCR_POINTS_PER_THREAD ||
+        hdr[4] != PCR_CLUSTERS_PER_THREAD || dt_size != PCR_HUFFMAN_TABLE_SIZE || num_clusters != PCR_CLUSTERS_PER_BATCH)
+        return set_err(c, PCR_E_FORMAT, "batch %lld: unsupported geometry (points %d threads %d ppt %d cpt %d table %d clusters %d)",
+                       (long long)batch_index, hdr[1], hdr[2], hdr[3], hdr[4], dt_size, num_clusters);
+    const uint8_t *p_start = r + PCR_BATCH_FIXED_HEADER;
+    const uint8_t *p_sepsz = p_start + 3072 * 4;
+    const uint8_t *p_tv = p_sepsz + 1024 * 4;
+    const uint8_t *p_tl = p_tv + 4096 * 4;
+    const uint8_t *p_cl = p_tl + 4096 * 4;
+    const uint8_t *p_enc = p_cl + 32 * 4;
+    int32_t ne, ns;
+    std::memcpy(&ne, p_cl + 31 * 4, 4);
+    std::memcpy(&ns, p_sepsz + 1023 * 4, 4);
+    if (ne < 64 || ns < 0 || n != fixed + 4u * ((size_t)ne + (size_t)ns) + PCR_COLOR_BYTES_PER_BATCH)   // BatchDumpData.h:148
+        return set_err(c, PCR_E_FORMAT, "batch %lld: record size %zu does not match its stream lengths", (long long)batch_index, n);
+    if (c->enc_ptr + ne > c->enc_words - PCR_ENCODED_PAD_WORDS || c->sep_ptr + ns > c->sep_words - PCR_SEPARATE_PAD_WORDS)
+        return set_err(c, PCR_E_FORMAT, "batch %lld: streams exceed the header's byte counts", (long long)batch_index);
+    // table lengths: validate and narrow to int8 (render.cu:393 narrows to char in-kernel)
+    c->lens_scratch.resize(4096);
+    for (int i = 0; i < 4096; ++i) {
+        int32_t l; std::memcpy(&l, p_tl + 4 * i, 4);
+        if (l == 0 || l > PCR_MAX_CW_LEN || l < -PCR_MAX_CW_LEN)
+            return set_err(c, PCR_E_FORMAT, "batch %lld: decoder table entry %d has code length %d", (long long)batch_index, i, l);
+        c->lens_scratch[(size_t)i] = (int8_t)l;
+    }
+    // monotone prefixes keep every in-range read inside the batch's own data
+    {
+        int32_t prev = 0;
+        for (int i = 0; i < 32; ++i) { int32_t v; std::memcpy(&v, p_cl + 4 * i, 4); if (v < prev) return set_err(c, PCR_E_FORMAT, "batch %lld: cluster sizes not monotone", (long long)batch_index); prev = v; }
+        prev = 0;
+        for (int i = 0; i < 1024; ++i) { int32_t v; std::memcpy(&v, p_sepsz + 4 * i, 4); if (v < prev) return set_err(c, PCR_E_FORMAT, "batch %lld: separate sizes not monotone", (long long)batch_index); prev = v; }
+    }
+    const uint8_t *p_sep = p_enc + (size_t)ne * 4;
+    const uint8_t *p_col = p_sep + (size_t)ns * 4;
+
+    pcr_gpu_batch g;                                  // HuffmanLasLoader.cpp:188-211
+    g.min_x = bmin[0]; g.min_y = bmin[1]; g.min_z = bmin[2];
+    g.max_x = bmax[0]; g.max_y = bmax[1]; g.max_z = bmax[2];
+    g.scale_x = sc[0]; g.scale_y = sc[1]; g.scale_z = sc[2];
+    g.offset_x = of[0]; g.offset_y = of[1]; g.offset_z = of[2];
+    g.las_min_x = lmin[0]; g.las_min_y = lmin[1]; g.las_min_z = lmin[2];
+    g.las_max_x = lmax[0]; g.las_max_y = lmax[1]; g.las_max_z = lmax[2];
+    g.encoding_batch_offset = c->enc_ptr;
+    g.separate_batch_offset = c->sep_ptr;
+    g.decoder_table_offset = batch_index * 4096;
+    g.cluster_sizes_offset = batch_index * 32;
+    g.max_cw_len = PCR_MAX_CW_LEN;
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t b = (size_t)batch_index;
+    hipStream_t st = c->stream;
+    // pageable-source async copies are staged by the runtime before returning, so `blob` may be released after the call
+    HIP_TRY(c, hipMemcpyAsync(c->d_batches + b, &g, sizeof g, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_start + b * 3072, p_start, 3072 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_sep_sizes + b * 1024, p_sepsz, 1024 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_table_values + b * 4096, p_tv, 4096 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_table_lens + b * 4096, c->lens_scratch.data(), 4096, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cluster_sizes + b * 32, p_cl, 32 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_encoded + c->enc_ptr, p_enc, (size_t)ne * 4, hipMemcpyHostToDevice, st));
+    if (ns) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, p_sep, (size_t)ns * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_colors + b * PCR_COLOR_BYTES_PER_BATCH, p_col, PCR_COLOR_BYTES_PER_BATCH, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));             // lens_scratch and `blob` are reusable on return
+    c->enc_ptr += ne; c->sep_ptr += ns;
+    c->batches_loaded += 1; c->points_loaded += hdr[1];   // HuffmanLasLoader.cpp:294-295
+    return PCR_OK;
+}
+
+int pcr_upload_tail(pcr_ctx *c, const uint32_t *enc, size_t n_enc, const int32_t *sep, size_t n_sep)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->stream_open) return set_err(c, PCR_E_ARG, "no stream");
+    if (n_enc > PCR_ENCODED_PAD_WORDS || n_sep > PCR_SEPARATE_PAD_WORDS)
+        return set_err(c, PCR_E_ARG, "tail larger than the pads (%d / %d words)", PCR_ENCODED_PAD_WORDS, PCR_SEPARATE_PAD_WORDS);
+    if ((size_t)(c->enc_words - c->enc_ptr) < n_enc || (size_t)(c->sep_words - c->sep_ptr) < n_sep)
+        return set_err(c, PCR_E_ARG, "tail does not fit behind the uploaded batches");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_enc) HIP_TRY(c, hipMemcpyAsync(c->d_encoded + c->enc_ptr, enc, n_enc * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_sep) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, sep, n_sep * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+int pcr_stream_unload(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_stream_buffers(c);
+    return PCR_OK;
+}
+
+int64_t pcr_batches_loaded(const pcr_ctx *c) { return c ? c->batches_loaded : 0; }
+int64_t pcr_points_loaded(const pcr_ctx *c) { return c ? c->points_loaded : 0; }
+
+int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
+{
+    if (!c || !c->stream_open) return 0;
+    // every compressed byte once + per-batch side data (GPUBatch + start values + escape prefix + table
+    // as stored here: 16 KiB values + 4 KiB lengths) + cluster prefix
+    const int64_t per_batch = 160 + 12288 + 4096 + (16384 + 4096) + 128;
+    return c->enc_ptr * 4 + c->sep_ptr * 4 + c->batches_loaded * per_batch;
+}
+
+// ---- method ------------------------------------------------------------------------------------
+int pcr_set_image_size(pcr_ctx *c, int w, int h)
+{
+    if (!c) return PCR_E_ARG;
+    if (w <= 0 || h <= 0 || (int64_t)w * (h + 1) + 1 > 0x7FFFFFFF) return set_err(c, PCR_E_ARG, "bad image size %dx%d", w, h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool external = c->fb && c->fb != c->own_fb;
+    if (external) return set_err(c, PCR_E_ARG, "release external buffers before resizing");
+    free_frame_buffers(c);
+    c->width = w; c->height = h; c->fb_elems = pcr_fb_elems(w, h);
+    HIP_TRY(c, hipMalloc((void **)&c->own_fb, c->fb_elems * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->own_rg, c->fb_elems * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->own_ba, c->fb_elems * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rgba, (size_t)w * h * 4));
+    c->fb = c->own_fb; c->rg = c->own_rg; c->ba = c->own_ba;
+    return pcr_clear(c);
+}
+
+int pcr_clear(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->fb, 0xFF, c->fb_elems * 8, c->stream));      // huffman_hqs.h:267
+    if (c->rg) HIP_TRY(c, hipMemsetAsync(c->rg, 0, c->fb_elems * 8, c->stream));   // :268
+    if (c->ba) HIP_TRY(c, hipMemsetAsync(c->ba, 0, c->fb_elems * 8, c->stream));   // :269
+    return PCR_OK;
+}
+
+int pcr_render_basic(pcr_ctx *c, const pcr_render_params *p) { return launch_render<MODE_BASIC>(c, p); }
+int pcr_render_hqs_depth(pcr_ctx *c, const pcr_render_params *p) { return launch_render<MODE_HQS_DEPTH>(c, p); }
+int pcr_render_hqs_color(pcr_ctx *c, const pcr_render_params *p)
+{
+    if (c && (!c->rg || !c->ba)) return set_err(c, PCR_E_ARG, "no RG/BA accumulation buffers");
+    return launch_render<MODE_HQS_COLOR>(c, p);
+}
+
+static int launch_resolve(pcr_ctx *c, const pcr_render_params *p, bool hqs)
+{
+    if (!c) return PCR_E_ARG;
+    if (!p) return set_err(c, PCR_E_ARG, "params are NULL");
+    if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
+    if (p->width != c->width || p->height != c->height) return set_err(c, PCR_E_ARG, "params image size != framebuffer");
+    dim3 grid((unsigned)((c->width + 15) / 16), (unsigned)((c->height + 15) / 16));   // huffman_hqs.h:249-250
+    if (hqs) hipLaunchKernelGGL(k_resolve<true>, grid, dim3(256), 0, c->stream, p->show_num_points, p->colorize_chunks, c->width, c->height, c->fb, c->rg, c->ba, c->d_rgba);
+    else     hipLaunchKernelGGL(k_resolve<false>, grid, dim3(256), 0, c->stream, p->show_num_points, p->colorize_chunks, c->width, c->height, c->fb, c->rg, c->ba, c->d_rgba);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+int pcr_resolve_basic(pcr_ctx *c, const pcr_render_params *p) { return launch_resolve(c, p, false); }
+int pcr_resolve_hqs(pcr_ctx *c, const pcr_render_params *p) { return launch_resolve(c, p, true); }
+
+int pcr_get_stats(pcr_ctx *c, pcr_render_stats *out)
+{
+    if (!c || !out) return PCR_E_ARG;
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_stats, sizeof *out, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+int pcr_read_framebuffer(pcr_ctx *c, uint64_t *host, size_t n)
+{
+    if (!c || !host) return PCR_E_ARG;
+    if (!c->fb || n > c->fb_elems) return set_err(c, PCR_E_ARG, "bad framebuffer read of %zu elements", n);
+    HIP_TRY(c, hipMemcpyAsync(host, c->fb, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+int pcr_read_accum(pcr_ctx *c, uint64_t *hrg, uint64_t *hba, size_t n)
+{
+    if (!c || !hrg || !hba) return PCR_E_ARG;
+    if (!c->rg || !c->ba || n > c->fb_elems) return set_err(c, PCR_E_ARG, "bad accumulation read");
+    HIP_TRY(c, hipMemcpyAsync(hrg, c->rg, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hba, c->ba, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+int pcr_read_rgba(pcr_ctx *c, uint32_t *host, size_t n)
+{
+    if (!c || !host) return PCR_E_ARG;
+    if (!c->d_rgba || n > (size_t)c->width * c->height) return set_err(c, PCR_E_ARG, "bad rgba read");
+    HIP_TRY(c, hipMemcpyAsync(host, c->d_rgba, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PCR_OK;
+}
+
+// ---- multi-GPU plumbing ------------------------------------------------------------------------
+void *pcr_device_framebuffer(pcr_ctx *c) { return c ? c->fb : nullptr; }
+void *pcr_device_rg(pcr_ctx *c) { return c ? c->rg : nullptr; }
+void *pcr_device_ba(pcr_ctx *c) { return c ? c->ba : nullptr; }
+
+int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->own_fb) return set_err(c, PCR_E_ARG, "call pcr_set_image_size first");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->fb = fb ? (uint64_t *)fb : c->own_fb;
+    c->rg = rg ? (uint64_t *)rg : c->own_rg;
+    c->ba = ba ? (uint64_t *)ba : c->own_ba;
+    return PCR_OK;
+}
+
+int pcr_merge_min(pcr_ctx *c, const void *other)
+{
+    if (!c || !other) return PCR_E_ARG;
+    if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
+    hipLaunchKernelGGL(k_merge_min, dim3(2048), dim3(256), 0, c->stream, c->fb, (const uint64_t *)other, (uint32_t)c->fb_elems);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_merge_sum(pcr_ctx *c, const void *org, const void *oba)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->rg || !c->ba) return set_err(c, PCR_E_ARG, "no accumulation buffers");
+    if (org) hipLaunchKernelGGL(k_merge_sum, dim3(2048), dim3(256), 0, c->stream, c->rg, (const uint64_t *)org, (uint32_t)c->fb_elems);
+    if (oba) hipLaunchKernelGGL(k_merge_sum, dim3(2048), dim3(256), 0, c->stream, c->ba, (const uint64_t *)oba, (uint32_t)c->fb_elems);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_flip_sign(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
+    hipLaunchKernelGGL(k_flip_sign, dim3(2048), dim3(256), 0, c->stream, c->fb, (uint32_t)c->fb_elems);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+int pcr_timing_begin(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
+    return PCR_OK;
+}
+
+int pcr_timing_end(pcr_ctx *c, float *ms)
+{
+    if (!c || !ms) return PCR_E_ARG;
+    HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev_end));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
+    return PCR_OK;
+}
+
+} // extern "C"

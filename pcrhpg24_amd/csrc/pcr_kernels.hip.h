@@ -1,0 +1,361 @@
+// pcr_kernels.hip.h — hand-written HIP kernels for gfx950 (MI355X, wave64). Included by pcr_api.hip only.
+//
+// Compile flags that are part of the numeric contract: -ffp-contract=off (every FMA
+// below is spelled __fmaf_rn/__fma_rn), default correctly-rounded f32 division and sqrt, no fast-math.
+//
+// Kernels
+//   k_lod_prepass   one thread per batch: frustum cull + LOD (render.cu:333-379) -> lod word per batch + stats
+//   k_render<MODE>  one 1024-thread workgroup per batch = 16 wave64 = 32 clusters of 32 chains; each lane
+//                   decodes its chain of <= 64 points from the cluster-interleaved stream with the batch's
+//                   decoder table in LDS, then projects and scatters every point (render.cu:383-540,
+//                   huffman_hqs/depth.cu, huffman_hqs/render.cu)
+//   k_resolve_*     framebuffer -> RGBA8 (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
+//   k_merge_* / k_flip_sign  multi-GPU partial-framebuffer merges
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pcr_types.h"
+
+namespace pcr {
+
+// lod word written by the prepass
+constexpr uint32_t LOD_NPR_MASK = 0xFFu;
+constexpr uint32_t LOD_DOUBLE   = 0x100u;
+constexpr uint32_t LOD_CULLED   = 0x200u;
+
+enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2 };
+
+// Device-side view of the loaded stream (own layout; the reference keeps nine flat CuBuffers,
+// HuffmanLasLoader.h:39-47). Tables are stored as int32 values + int8 lengths (the reference narrows the
+// length to `char` in-kernel, render.cu:393).
+struct StreamView {
+    const pcr_gpu_batch *batches;
+    const int32_t  *start_values;     // [nB*1024*3]
+    const uint32_t *encoded;          // [encoded_words]   (includes zero pad)
+    const int32_t  *separate;         // [separate_words]  (includes zero pad)
+    const int32_t  *separate_sizes;   // [nB*1024]
+    const int32_t  *table_values;     // [nB*4096]
+    const int8_t   *table_lens;       // [nB*4096]
+    const int32_t  *cluster_sizes;    // [nB*32]
+    const uint8_t  *colors;           // [nB*32768]
+    int64_t encoded_words;
+    int64_t separate_words;
+    int64_t num_batches;
+    int64_t batch_index_base;
+};
+
+struct FrameView {
+    uint64_t *fb;
+    uint64_t *rg;
+    uint64_t *ba;
+    uint32_t  fb_elems;
+};
+
+struct RenderArgs {
+    pcr_render_params p;
+    StreamView s;
+    FrameView f;
+    uint32_t *lod;            // [nB]
+    pcr_render_stats *stats;  // device
+    int variant_hqs;          // LOD expression variant
+};
+
+// ------------------------------------------------------------------------------------------------
+// strict-float helpers (helper_math.h semantics, Appendix C.1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot4(const float *r, float x, float y, float z, float w)
+{
+    return __fmaf_rn(r[3], w, __fmaf_rn(r[2], z, __fmaf_rn(r[1], y, r[0] * x)));
+}
+
+__device__ __forceinline__ bool plane_accepts(float x, float y, float z, float w, const float *bmin, const float *bmax)
+{
+    float nl = sqrtf(__fmaf_rn(z, z, __fmaf_rn(y, y, x * x)));      // createPlane, render.cu:239-246
+    float nx = x / nl, ny = y / nl, nz = z / nl, c = w / nl;
+    float vx = nx > 0.0f ? bmax[0] : bmin[0];                       // :261-264
+    float vy = ny > 0.0f ? bmax[1] : bmin[1];
+    float vz = nz > 0.0f ? bmax[2] : bmin[2];
+    float d = __fmaf_rn(nz, vz, __fmaf_rn(ny, vy, nx * vx)) + c;    // :235-237
+    return !(d < 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepass: cull + LOD per batch
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.s.num_batches) return;
+    const pcr_gpu_batch g = a.s.batches[b];
+    const pcr_render_params &p = a.p;
+    const float lm[3] = { (float)g.las_min_x, (float)g.las_min_y, (float)g.las_min_z };      // :336
+    const float bmin[3] = { g.min_x - lm[0], g.min_y - lm[1], g.min_z - lm[2] };             // :340
+    const float bmax[3] = { g.max_x - lm[0], g.max_y - lm[1], g.max_z - lm[2] };             // :341
+
+    atomicAdd((unsigned long long *)&a.stats->batches_total, 1ull);
+    if (p.enable_frustum_culling) {                                                          // :342-344
+        const float *M = p.transform;
+#define T(i) M[((i) % 4) * 4 + ((i) / 4)]
+        bool in = plane_accepts(T(3) - T(0), T(7) - T(4), T(11) - T(8),  T(15) - T(12), bmin, bmax)
+               && plane_accepts(T(3) + T(0), T(7) + T(4), T(11) + T(8),  T(15) + T(12), bmin, bmax)
+               && plane_accepts(T(3) + T(1), T(7) + T(5), T(11) + T(9),  T(15) + T(13), bmin, bmax)
+               && plane_accepts(T(3) - T(1), T(7) - T(5), T(11) - T(9),  T(15) - T(13), bmin, bmax)
+               && plane_accepts(T(3) - T(2), T(7) - T(6), T(11) - T(10), T(15) - T(14), bmin, bmax)
+               && plane_accepts(T(3) + T(2), T(7) + T(6), T(11) + T(10), T(15) + T(14), bmin, bmax);
+#undef T
+        if (!in) {
+            a.lod[b] = LOD_CULLED;
+            atomicAdd((unsigned long long *)&a.stats->batches_culled, 1ull);
+            return;
+        }
+    }
+    // :349-375
+    const float cx = 0.5f * (bmin[0] + bmax[0]), cy = 0.5f * (bmin[1] + bmax[1]), cz = 0.5f * (bmin[2] + bmax[2]);
+    const float dx = bmin[0] - bmax[0], dy = bmin[1] - bmax[1], dz = bmin[2] - bmax[2];
+    const float rad = sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+    float vc[4], ve[4], pc[4], pe[4];
+    for (int r = 0; r < 4; ++r) vc[r] = dot4(p.world_view + 4 * r, cx, cy, cz, 1.0f);
+    ve[0] = vc[0] + rad; ve[1] = vc[1] + 0.0f; ve[2] = vc[2] + 0.0f; ve[3] = vc[3] + 0.0f;
+    for (int r = 0; r < 4; ++r) {
+        pc[r] = dot4(p.proj + 4 * r, vc[0], vc[1], vc[2], vc[3]);
+        pe[r] = dot4(p.proj + 4 * r, ve[0], ve[1], ve[2], ve[3]);
+    }
+    const float fw = (float)p.width, fh = (float)p.height;
+    const float scx = fw * (0.5f * (pc[0] / pc[3] + 1.0f)), scy = fh * (0.5f * (pc[1] / pc[3] + 1.0f));
+    const float sex = fw * (0.5f * (pe[0] / pe[3] + 1.0f)), sey = fh * (0.5f * (pe[1] / pe[3] + 1.0f));
+    const float ddx = sex - scx, ddy = sey - scy;
+    float px = sqrtf(__fmaf_rn(ddy, ddy, ddx * ddx));
+    const bool use_double = px >= 100.0f;                                    // :370
+    if (a.variant_hqs) px = (float)((double)px / 100.0);                     // hqs depth.cu:223 / render.cu:388
+    else               px = px / 100.0f;                                     // mem_iter render.cu:372
+    float pct = (float)((double)(1.8f * px) - 0.3);                          // :373
+    pct = fmaxf((float)p.lod_percent / 100.0f, fminf(pct, 1.0f));            // :374
+    int npr = (int)(pct * (float)p.points_per_thread);                       // :375
+    npr = min(npr, p.points_per_thread);
+    npr = max(npr, 0);
+    a.lod[b] = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
+    atomicAdd((unsigned long long *)&a.stats->points_iterated, (unsigned long long)npr * PCR_WORKGROUP_SIZE);
+    if (use_double) atomicAdd((unsigned long long *)&a.stats->batches_double, 1ull);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BC1 (render.cu:23-65), always 4-colour mode
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t decode_bc1(uint32_t point_index, const uint8_t *colors)
+{
+    const uint2 blk = *reinterpret_cast<const uint2 *>(colors + (size_t)(point_index >> 4) * 8);
+    const uint32_t local = point_index & 15u;
+    const uint32_t l = blk.x & 0xFFFFu, h = blk.x >> 16;
+    const int cr0 = (l >> 11) & 31, cg0 = (l >> 5) & 63, cb0 = l & 31;
+    const int r0 = (cr0 << 3) | (cr0 >> 2), g0 = (cg0 << 2) | (cg0 >> 4), b0 = (cb0 << 3) | (cb0 >> 2);
+    const int cr1 = (h >> 11) & 31, cg1 = (h >> 5) & 63, cb1 = h & 31;
+    const int r1 = (cr1 << 3) | (cr1 >> 2), g1 = (cg1 << 2) | (cg1 >> 4), b1 = (cb1 << 3) | (cb1 >> 2);
+    const uint32_t sel = (blk.y >> (2 * local)) & 3u;   // byte 4 + local/4, bits 2*(local%4)
+    int r, g, b;
+    if (sel == 0)      { r = r0; g = g0; b = b0; }
+    else if (sel == 1) { r = r1; g = g1; b = b1; }
+    else if (sel == 2) { r = (r0 * 2 + r1) / 3; g = (g0 * 2 + g1) / 3; b = (b0 * 2 + b1) / 3; }
+    else               { r = (r0 + r1 * 2) / 3; g = (g0 + g1 * 2) / 3; b = (b0 + b1 * 2) / 3; }
+    return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// project + scatter one point (render.cu:276-303; hqs depth.cu:127-154; hqs render.cu:274-316)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void rasterize(const RenderArgs &a, float x, float y, float z,
+                                          uint32_t local_point_index, uint32_t payload)
+{
+    const float *M = a.p.transform;
+    const float px = dot4(M + 0, x, y, z, 1.0f);
+    const float py = dot4(M + 4, x, y, z, 1.0f);
+    const float pw = dot4(M + 12, x, y, z, 1.0f);
+    const float nx = px / pw, ny = py / pw;
+    // inside test (:296), NaN-rejecting form
+    if (!(pw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f)) return;
+    const float ix = __fmaf_rn(nx, 0.5f, 0.5f) * (float)a.p.width;   // :283
+    const float iy = __fmaf_rn(ny, 0.5f, 0.5f) * (float)a.p.height;
+    const uint32_t pix = (uint32_t)((int)ix + (int)iy * a.p.width);  // :284-285
+    if (pix >= a.f.fb_elems) return;
+    const uint32_t depth = __float_as_uint(pw);                      // :287
+
+    if (MODE == MODE_HQS_COLOR) {
+        const uint64_t old = a.f.fb[pix];
+        const float old_depth = __uint_as_float((uint32_t)(old >> 32));
+        if ((double)pw <= (double)old_depth * 1.01) {                // hqs render.cu:296
+            const uint32_t rgba = decode_bc1(local_point_index, a.s.colors);
+            const uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
+            atomicAdd((unsigned long long *)&a.f.rg[pix], (unsigned long long)((r << 32) | g));    // :309-310
+            atomicAdd((unsigned long long *)&a.f.ba[pix], (unsigned long long)((b << 32) | 1u));   // :311-312
+        }
+    } else if (MODE == MODE_BASIC) {
+        // Pre-read filter (:297-298) on the depth half only, so the result is exactly
+        // min(depth<<32|colour) over all inside points (Appendix C.5).
+        const uint64_t hi = (uint64_t)depth << 32;
+        const uint64_t old = a.f.fb[pix];
+        if (hi <= (old | 0xFFFFFFFFull)) {
+            const uint64_t key = hi | decode_bc1(local_point_index, a.s.colors);                   // :299
+            if (key < old) atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key); // :300
+        }
+    } else {
+        const uint64_t key = ((uint64_t)depth << 32) | payload;                                    // depth.cu:139-145
+        const uint64_t old = a.f.fb[pix];
+        if (key < old) atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);     // :148-151
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode + rasterize: one workgroup per batch
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t lod = a.lod[b];
+    if (lod & LOD_CULLED) return;
+    const int npr = (int)(lod & LOD_NPR_MASK);
+    const bool use_double = (lod & LOD_DOUBLE) != 0;
+    const uint32_t tid = threadIdx.x;
+
+    // decoder table -> LDS as {value, len} pairs so one ds_read_b64 serves a symbol (render.cu:383-395)
+    __shared__ int2 s_table[PCR_HUFFMAN_TABLE_SIZE];
+    {
+        const int4 v = reinterpret_cast<const int4 *>(a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+        const uint32_t l4 = reinterpret_cast<const uint32_t *>(a.s.table_lens + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+        s_table[tid * 4 + 0] = make_int2(v.x, (int)(int8_t)(l4 & 0xFF));
+        s_table[tid * 4 + 1] = make_int2(v.y, (int)(int8_t)((l4 >> 8) & 0xFF));
+        s_table[tid * 4 + 2] = make_int2(v.z, (int)(int8_t)((l4 >> 16) & 0xFF));
+        s_table[tid * 4 + 3] = make_int2(v.w, (int)(int8_t)(l4 >> 24));
+    }
+
+    const pcr_gpu_batch *gb = a.s.batches + b;
+    const int64_t enc_off = gb->encoding_batch_offset;      // :404
+    const int64_t sep_off = gb->separate_batch_offset;      // :405
+    const uint32_t *enc = a.s.encoded + enc_off;            // batch-relative base (uniform)
+    const int32_t *sep = a.s.separate + sep_off;
+    // reads past the allocation (zero pad included) are defined as 0
+    const uint32_t enc_limit = (uint32_t)min((int64_t)0x7FFFFFFF, a.s.encoded_words - enc_off);
+    const uint32_t sep_limit = (uint32_t)min((int64_t)0x7FFFFFFF, a.s.separate_words - sep_off);
+
+    const uint32_t cluster = tid >> 5;                      // 32-lane cluster of the stream format
+    const uint32_t lane32 = tid & 31u;
+    const uint32_t half_shift = tid & 32u;                  // which half of the wave64 ballot is mine
+    const uint32_t lanes_below = (1u << lane32) - 1u;       // (CUDA's mask << (32 - tid), without the shift-by-32)
+
+    uint32_t ep = cluster ? (uint32_t)a.s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;    // :407-410
+    uint32_t sp = tid ? (uint32_t)a.s.separate_sizes[(size_t)b * 1024 + tid - 1] : 0u;         // :411-413
+    auto enc_load = [&](uint32_t i) -> uint32_t { return i < enc_limit ? enc[i] : 0u; };
+    auto sep_load = [&](uint32_t i) -> int32_t { return i < sep_limit ? sep[i] : 0; };
+
+    uint32_t cur = enc_load(ep + lane32);                   // :416
+    uint32_t nxt = enc_load(ep + 32 + lane32);              // :417
+    ep += 64;                                               // == EncodedPtr + already_read (:418)
+    int cur_bits = 32;                                      // :419
+    const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + tid) * 3;   // :421-424
+    int32_t px = sv[0], py = sv[1], pz = sv[2];
+
+    const double sx = gb->scale_x, sy = gb->scale_y, sz = gb->scale_z;
+    const double ox = gb->offset_x - gb->las_min_x, oy = gb->offset_y - gb->las_min_y, oz = gb->offset_z - gb->las_min_z;
+    const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;          // :469
+    const float fox = (float)ox, foy = (float)oy, foz = (float)oz;          // :470
+
+    uint32_t payload = 0;
+    if (MODE == MODE_HQS_DEPTH) {
+        if (a.p.show_num_points)      payload = (uint32_t)npr;                                   // depth.cu:139-140
+        else if (a.p.colorize_chunks) payload = (uint32_t)(a.s.batch_index_base + b);            // :141-142
+    }
+    const uint32_t point_base = b * PCR_POINTS_PER_BATCH + tid * PCR_POINTS_PER_THREAD;          // :453
+
+    __syncthreads();
+
+    for (int i = 0; i < npr; ++i) {                                         // :428
+        int32_t dec[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                                       // :430
+            // 12-bit window at the read position: == ((L|R) & mask) >> 20 of :431-433
+            const uint64_t w = ((uint64_t)cur << 32) | nxt;
+            const uint32_t key = (uint32_t)(w >> (20 + cur_bits)) & 0xFFFu;
+            const int2 e = s_table[key];                                    // :435-436
+            int32_t val = e.x;
+            const int len = e.y;
+            if (len <= 0) { val = sep_load(sp); ++sp; }                     // :438
+            cur_bits -= abs(len);                                           // :439
+            const bool need = cur_bits <= 0;                                // :442
+            const uint64_t m = __ballot(need);                              // :443
+            const uint32_t mh = (uint32_t)(m >> half_shift);
+            if (need) {                                                     // :444-449
+                cur = nxt;
+                nxt = enc_load(ep + __popc(mh & lanes_below));
+                cur_bits += 32;
+            }
+            ep += __popc(mh);                                               // :450
+            dec[j] = val;
+        }
+        px += dec[0]; py += dec[1]; pz += dec[2];                           // :454-456, :463
+        float x, y, z;
+        if (use_double) {                                                   // :459-461
+            x = (float)__fma_rn((double)px, sx, ox);
+            y = (float)__fma_rn((double)py, sy, oy);
+            z = (float)__fma_rn((double)pz, sz, oz);
+        } else {                                                            // :529-531
+            x = __fmaf_rn((float)px, fsx, fox);
+            y = __fmaf_rn((float)py, fsy, foy);
+            z = __fmaf_rn((float)pz, fsz, foz);
+        }
+        rasterize<MODE>(a, x, y, z, point_base + (uint32_t)i, payload);     // :465
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resolve (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
+// ------------------------------------------------------------------------------------------------
+template <bool HQS>
+__global__ void __launch_bounds__(256) k_resolve(int show_num_points, int colorize_chunks, int width, int height,
+                                                 const uint64_t *fb, const uint64_t *rg, const uint64_t *ba,
+                                                 uint32_t *rgba)
+{
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15);     // 16x16 tiles as the reference launches
+    const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= width || y >= height) return;
+    const int pix = x + y * width;
+    const uint32_t id = (uint32_t)fb[pix];
+    uint32_t color = PCR_BACKGROUND_COLOR;
+    if (id < 0xFFFFFFFFu) {
+        if (show_num_points) {
+            const double div = HQS ? 512.0 : 64.0;
+            const uint32_t shade = (uint32_t)(((double)(float)(int)id / div) * 255.0);
+            color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+        } else if (colorize_chunks) {
+            color = id * 1234567u;
+        } else if (HQS) {
+            const uint64_t vrg = rg[pix], vba = ba[pix];
+            const uint32_t cnt = (uint32_t)vba;
+            if (cnt == 0) color = 0;
+            else color = (((uint32_t)(vba >> 32) / cnt) << 16) | (((uint32_t)vrg / cnt) << 8) | ((uint32_t)(vrg >> 32) / cnt);
+        } else {
+            color = id;
+        }
+    }
+    rgba[pix] = color;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU merges
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_merge_min(uint64_t *dst, const uint64_t *src, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = min(dst[i], src[i]);
+}
+__global__ void __launch_bounds__(256) k_merge_sum(uint64_t *dst, const uint64_t *src, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+__global__ void __launch_bounds__(256) k_flip_sign(uint64_t *dst, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] ^= 0x8000000000000000ull;
+}
+
+} // namespace pcr

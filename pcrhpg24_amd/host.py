@@ -1,0 +1,511 @@
+"""Host-side mirror of the reference's plugin surface for the Huffman path, over the C ABI.
+
+The names, call order and error behaviour follow the reference so the parity tests read like a session
+of the reference viewer without a window:
+
+    Method   {name, description, group, update(renderer), render(renderer)}     include/Method.h:10-23
+    Resource {state, load(renderer), unload(renderer), process(renderer)}        modules/compute/Resources.h:27-35
+    HuffmanLasData.create(path)                                                  modules/compute/HuffmanLasLoader.h:87-92
+    HuffmanMemIter  ("huffman_mem_iter_cuda")                                    modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h
+    HuffmanHQS      ("huffman_hqs")                                              modules/huffman_hqs/huffman_hqs.h
+    Runtime.addMethod / setSelectedMethod / resource                             include/Runtime.h:15-55
+    Debug.LOD / frustumCullingEnabled / colorizeChunks / showNumPoints           include/Debug.h:14-31
+
+Python here is plumbing only (ctypes calls, byte slicing); all compute is in libpcr_hip.so /
+libpcr_host.so. A C++ twin of these adapters lives in csrc/pcr_methods.hpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import mmap
+import os
+import struct
+from typing import Iterator, Optional
+
+import numpy as np
+
+from . import _native as N
+from ._native import EncodeStats, FileHeader, LasInfo, RenderParams, RenderStats, fb_elems
+
+POINTS_PER_BATCH = 65536
+ENCODED_PAD_WORDS = 1024
+SEPARATE_PAD_WORDS = 256
+BATCH_FIXED_HEADER = 124
+_BATCH_FIXED = BATCH_FIXED_HEADER + 4 * (3072 + 1024 + 4096 + 4096 + 32)
+
+
+class PcrError(RuntimeError):
+    pass
+
+
+# --------------------------------------------------------------------------------------------------
+# native buffers / encoder front-ends (libpcr_host.so)
+# --------------------------------------------------------------------------------------------------
+class NativeBytes:
+    """A malloc'ed byte buffer owned by libpcr_host.so, exposed through the buffer protocol."""
+
+    def __init__(self, ptr: int, length: int):
+        self._ptr, self._len = ptr, length
+        self._arr = (C.c_uint8 * length).from_address(ptr)
+
+    def __len__(self) -> int:
+        return self._len
+
+    def view(self) -> memoryview:
+        return memoryview(self._arr).cast("B")
+
+    def free(self) -> None:
+        if self._ptr:
+            self._arr = None
+            N.host_lib().pcr_host_free(C.c_void_p(self._ptr))
+            self._ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synth_encode(total_points: int, seed: int = 0x5EED, first: int = 0, count: Optional[int] = None,
+                 chunk_points: int = 0, nthreads: int = 0) -> tuple[NativeBytes, dict]:
+    """Generate + encode points [first, first+count) of the synthetic scene -> (.huffman image, stats)."""
+    lib = N.host_lib()
+    if count is None:
+        count = total_points - first
+    out, ln, st = C.c_void_p(), C.c_size_t(), EncodeStats()
+    rc = lib.pcr_synth_encode(total_points, seed, first, count, chunk_points, nthreads, C.byref(out), C.byref(ln), C.byref(st))
+    if rc:
+        raise PcrError(f"pcr_synth_encode: {N.host_error()}")
+    return NativeBytes(out.value, ln.value), st.as_dict()
+
+
+def synth_points(total_points: int, seed: int, first: int, count: int):
+    x = np.empty(count, np.int32); y = np.empty(count, np.int32); z = np.empty(count, np.int32)
+    c = np.empty(count, np.uint32)
+    rc = N.host_lib().pcr_synth_points(total_points, seed, first, count, x.ctypes.data, y.ctypes.data, z.ctypes.data, c.ctypes.data)
+    if rc:
+        raise PcrError(f"pcr_synth_points: {N.host_error()}")
+    return x, y, z, c
+
+
+def synth_las_info(total_points: int, seed: int = 0x5EED) -> LasInfo:
+    las = LasInfo()
+    N.host_lib().pcr_synth_las_info(total_points, seed, C.byref(las))
+    return las
+
+
+def encode_points(x, y, z, color, las: LasInfo, morton_sort: bool = True, chunk_points: int = 0,
+                  nthreads: int = 0) -> tuple[NativeBytes, dict]:
+    """`preprocess in.las out.huffman <sort>` on in-memory points (src/preprocess.cpp:1167-1279)."""
+    x = np.ascontiguousarray(x, np.int32); y = np.ascontiguousarray(y, np.int32); z = np.ascontiguousarray(z, np.int32)
+    color = np.ascontiguousarray(color, np.uint32)
+    out, ln, st = C.c_void_p(), C.c_size_t(), EncodeStats()
+    rc = N.host_lib().pcr_encode_points(x.ctypes.data, y.ctypes.data, z.ctypes.data, color.ctypes.data, len(x), C.byref(las),
+                                        int(morton_sort), chunk_points, nthreads, C.byref(out), C.byref(ln), C.byref(st))
+    if rc:
+        raise PcrError(f"pcr_encode_points: {N.host_error()}")
+    return NativeBytes(out.value, ln.value), st.as_dict()
+
+
+def camera_orbit(yaw: float, pitch: float, radius: float, target, width: int, height: int,
+                 fovy: float = 60.0, near: float = 0.1, far: float = 200000.0) -> RenderParams:
+    """OrbitControls + Camera + the ChangingRenderData setup of HuffmanHQS::render (huffman_hqs.h:157-183)."""
+    p = RenderParams()
+    t = (C.c_double * 3)(*target)
+    rc = N.host_lib().pcr_camera_orbit(yaw, pitch, radius, t, width, height, fovy, near, far, C.byref(p))
+    if rc:
+        raise PcrError(f"pcr_camera_orbit: {N.host_error()}")
+    return p
+
+
+# --------------------------------------------------------------------------------------------------
+# .huffman container (HuffmanLasData::loadHeader, HuffmanLasLoader.h:57-85)
+# --------------------------------------------------------------------------------------------------
+class HuffmanFile:
+    """Header + batch-record slicing of a .huffman image held in memory or memory-mapped from disk."""
+
+    def __init__(self, data):
+        self._mm = None
+        if isinstance(data, (str, os.PathLike)):
+            f = open(data, "rb")
+            self._mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            f.close()
+            data = self._mm
+        elif isinstance(data, NativeBytes):
+            self._keep = data
+            data = data.view()
+        self.buf = memoryview(data).cast("B")
+        if len(self.buf) < 40:
+            raise PcrError("file shorter than its 40-byte header")
+        (self.numPoints, self.numBatches, self.encodedBytes, self.separateBytes, self.clusterBytes) = \
+            struct.unpack_from("<5q", self.buf, 0)
+        if self.numBatches < 0 or len(self.buf) < 40 + 8 * self.numBatches:
+            raise PcrError("file shorter than its batch size table")
+        self.batch_data_sizes = np.frombuffer(self.buf, np.int64, self.numBatches, 40)
+        self.offsetToBatchData = 40 + 8 * self.numBatches
+        self.batch_offsets = self.offsetToBatchData + np.concatenate([[0], np.cumsum(self.batch_data_sizes)])
+        if int(self.batch_offsets[-1]) > len(self.buf):
+            raise PcrError("batch records exceed the file")
+
+    def header(self, first: int = 0, count: Optional[int] = None) -> FileHeader:
+        """Header of the whole file, or of the sub-stream of batches [first, first+count)."""
+        if count is None:
+            count = self.numBatches - first
+        if first == 0 and count == self.numBatches:
+            return FileHeader(self.numPoints, self.numBatches, self.encodedBytes, self.separateBytes, self.clusterBytes)
+        enc = sep = 0
+        for b in range(first, first + count):
+            ne, ns = self.stream_lengths(b)
+            enc += 4 * ne; sep += 4 * ns
+        return FileHeader(count * POINTS_PER_BATCH, count, enc, sep, 128 * count)
+
+    def blob(self, b: int) -> memoryview:
+        return self.buf[int(self.batch_offsets[b]):int(self.batch_offsets[b + 1])]
+
+    def stream_lengths(self, b: int) -> tuple[int, int]:
+        """(#encoded words, #escape words) of batch b, read from its inclusive prefixes."""
+        o = int(self.batch_offsets[b])
+        ns = struct.unpack_from("<i", self.buf, o + BATCH_FIXED_HEADER + 4 * 3072 + 4 * 1023)[0]
+        ne = struct.unpack_from("<i", self.buf, o + BATCH_FIXED_HEADER + 4 * (3072 + 1024 + 4096 + 4096) + 4 * 31)[0]
+        return ne, ns
+
+    def head_words(self, b: int) -> tuple[np.ndarray, np.ndarray]:
+        """First words of batch b's encoded / escape streams: the tail a shard ending before b must carry."""
+        ne, ns = self.stream_lengths(b)
+        o = int(self.batch_offsets[b]) + _BATCH_FIXED
+        enc = np.frombuffer(self.buf, np.uint32, min(ne, ENCODED_PAD_WORDS), o)
+        sep = np.frombuffer(self.buf, np.int32, min(ns, SEPARATE_PAD_WORDS), o + 4 * ne)
+        return enc, sep
+
+    def blobs(self, first: int = 0, count: Optional[int] = None) -> Iterator[memoryview]:
+        if count is None:
+            count = self.numBatches - first
+        for b in range(first, first + count):
+            yield self.blob(b)
+
+
+# --------------------------------------------------------------------------------------------------
+# C-ABI context wrapper
+# --------------------------------------------------------------------------------------------------
+class Context:
+    """Owns one pcr_ctx (one GPU, one stream)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = N.hip_lib()
+        h = C.c_void_p()
+        rc = self.lib.pcr_create(device, C.byref(h))
+        if rc:
+            raise PcrError(f"pcr_create({device}) -> {rc}: {(self.lib.pcr_last_error(None) or b'').decode()}")
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc: int, what: str) -> None:
+        if rc:
+            raise PcrError(f"{what} -> {rc}: {(self.lib.pcr_last_error(self.h) or b'').decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.pcr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # resource side
+    def stream_begin(self, hdr: FileHeader, batch_index_base: int = 0):
+        self._chk(self.lib.pcr_stream_begin(self.h, C.byref(hdr), batch_index_base), "pcr_stream_begin")
+
+    def upload_batch(self, index: int, blob) -> None:
+        mv = memoryview(blob).cast("B")
+        arr = np.frombuffer(mv, np.uint8)
+        self._chk(self.lib.pcr_upload_batch(self.h, index, arr.ctypes.data, len(mv)), "pcr_upload_batch")
+
+    def upload_tail(self, enc: np.ndarray, sep: np.ndarray) -> None:
+        enc = np.ascontiguousarray(enc, np.uint32); sep = np.ascontiguousarray(sep, np.int32)
+        self._chk(self.lib.pcr_upload_tail(self.h, enc.ctypes.data, len(enc), sep.ctypes.data, len(sep)), "pcr_upload_tail")
+
+    def stream_unload(self):
+        self._chk(self.lib.pcr_stream_unload(self.h), "pcr_stream_unload")
+
+    @property
+    def batches_loaded(self) -> int:
+        return int(self.lib.pcr_batches_loaded(self.h))
+
+    @property
+    def points_loaded(self) -> int:
+        return int(self.lib.pcr_points_loaded(self.h))
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(self.lib.pcr_stream_algorithmic_bytes(self.h))
+
+    # method side
+    def set_image_size(self, w: int, h: int):
+        self._chk(self.lib.pcr_set_image_size(self.h, w, h), "pcr_set_image_size")
+        self.width, self.height = w, h
+
+    def clear(self):
+        self._chk(self.lib.pcr_clear(self.h), "pcr_clear")
+
+    def render_basic(self, p: RenderParams):
+        self._chk(self.lib.pcr_render_basic(self.h, C.byref(p)), "pcr_render_basic")
+
+    def render_hqs_depth(self, p: RenderParams):
+        self._chk(self.lib.pcr_render_hqs_depth(self.h, C.byref(p)), "pcr_render_hqs_depth")
+
+    def render_hqs_color(self, p: RenderParams):
+        self._chk(self.lib.pcr_render_hqs_color(self.h, C.byref(p)), "pcr_render_hqs_color")
+
+    def resolve_basic(self, p: RenderParams):
+        self._chk(self.lib.pcr_resolve_basic(self.h, C.byref(p)), "pcr_resolve_basic")
+
+    def resolve_hqs(self, p: RenderParams):
+        self._chk(self.lib.pcr_resolve_hqs(self.h, C.byref(p)), "pcr_resolve_hqs")
+
+    def synchronize(self):
+        self._chk(self.lib.pcr_synchronize(self.h), "pcr_synchronize")
+
+    def stats(self) -> dict:
+        st = RenderStats()
+        self._chk(self.lib.pcr_get_stats(self.h, C.byref(st)), "pcr_get_stats")
+        return st.as_dict()
+
+    def read_framebuffer(self, full: bool = False) -> np.ndarray:
+        n = fb_elems(self.width, self.height) if full else self.width * self.height
+        out = np.empty(n, np.uint64)
+        self._chk(self.lib.pcr_read_framebuffer(self.h, out.ctypes.data, n), "pcr_read_framebuffer")
+        return out
+
+    def read_accum(self, full: bool = False):
+        n = fb_elems(self.width, self.height) if full else self.width * self.height
+        rg, ba = np.empty(n, np.uint64), np.empty(n, np.uint64)
+        self._chk(self.lib.pcr_read_accum(self.h, rg.ctypes.data, ba.ctypes.data, n), "pcr_read_accum")
+        return rg, ba
+
+    def read_rgba(self) -> np.ndarray:
+        n = self.width * self.height
+        out = np.empty(n, np.uint32)
+        self._chk(self.lib.pcr_read_rgba(self.h, out.ctypes.data, n), "pcr_read_rgba")
+        return out
+
+    # multi-GPU plumbing / measurement
+    def device_framebuffer(self) -> int:
+        return int(self.lib.pcr_device_framebuffer(self.h) or 0)
+
+    def use_external_buffers(self, fb: int = 0, rg: int = 0, ba: int = 0):
+        self._chk(self.lib.pcr_use_external_buffers(self.h, C.c_void_p(fb or None), C.c_void_p(rg or None), C.c_void_p(ba or None)),
+                  "pcr_use_external_buffers")
+
+    def set_stream(self, hip_stream: int):
+        self._chk(self.lib.pcr_set_stream(self.h, C.c_void_p(hip_stream or None)), "pcr_set_stream")
+
+    def merge_min(self, other_fb: int):
+        self._chk(self.lib.pcr_merge_min(self.h, C.c_void_p(other_fb)), "pcr_merge_min")
+
+    def merge_sum(self, other_rg: int, other_ba: int):
+        self._chk(self.lib.pcr_merge_sum(self.h, C.c_void_p(other_rg or None), C.c_void_p(other_ba or None)), "pcr_merge_sum")
+
+    def flip_sign(self):
+        self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
+
+    def timing_begin(self):
+        self._chk(self.lib.pcr_timing_begin(self.h), "pcr_timing_begin")
+
+    def timing_end(self) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.pcr_timing_end(self.h, C.byref(ms)), "pcr_timing_end")
+        return float(ms.value)
+
+
+# --------------------------------------------------------------------------------------------------
+# the reference's plugin surface, headless
+# --------------------------------------------------------------------------------------------------
+class Debug:                      # include/Debug.h:14-31 (the flags the Huffman methods read)
+    LOD = 0.1
+    frustumCullingEnabled = True
+    colorizeChunks = False
+    showNumPoints = False
+
+
+class Renderer:
+    """Headless stand-in for the reference Renderer: window size + orbit camera + one GPU context."""
+
+    def __init__(self, width: int = 1920, height: int = 1080, device: int = 0):   # Renderer.cpp:142-143
+        self.width, self.height = width, height
+        self.ctx = Context(device)
+        self.ctx.set_image_size(width, height)
+        self.yaw, self.pitch, self.radius, self.target = 0.0, 0.0, 10.0, (0.0, 0.0, 0.0)
+        self.params_override: Optional[RenderParams] = None
+
+    def set_camera(self, yaw, pitch, radius, target):
+        self.yaw, self.pitch, self.radius, self.target = yaw, pitch, radius, tuple(target)
+
+    def render_params(self) -> RenderParams:
+        p = self.params_override.copy() if self.params_override is not None else \
+            camera_orbit(self.yaw, self.pitch, self.radius, self.target, self.width, self.height)
+        p.lod_percent = int(Debug.LOD * 100)                       # huffman_hqs.h:177
+        p.enable_frustum_culling = int(Debug.frustumCullingEnabled)
+        p.colorize_chunks = int(Debug.colorizeChunks)
+        p.show_num_points = int(Debug.showNumPoints)
+        return p
+
+
+class Resource:                   # modules/compute/Resources.h:20-35
+    UNLOADED, LOADING, LOADED, UNLOADING = range(4)
+
+    def __init__(self):
+        self.state = Resource.UNLOADED
+
+    def load(self, renderer): raise NotImplementedError
+    def unload(self, renderer): raise NotImplementedError
+    def process(self, renderer): raise NotImplementedError
+
+
+class Method:                     # include/Method.h:10-23
+    name = "no name"
+    description = ""
+    group = "no group"
+
+    def update(self, renderer): raise NotImplementedError
+    def render(self, renderer): raise NotImplementedError
+
+
+class Runtime:                    # include/Runtime.h:15-55
+    methods: list = []
+    selectedMethod: Optional[Method] = None
+    resource: Optional[Resource] = None
+
+    @staticmethod
+    def addMethod(m: Method):
+        Runtime.methods.append(m)
+
+    @staticmethod
+    def setSelectedMethod(name: str):
+        for m in Runtime.methods:
+            if m.name == name:
+                Runtime.selectedMethod = m
+
+    @staticmethod
+    def getSelectedMethod():
+        return Runtime.selectedMethod
+
+    @staticmethod
+    def reset():
+        Runtime.methods, Runtime.selectedMethod, Runtime.resource = [], None, None
+
+
+class HuffmanLasData(Resource):
+    """modules/compute/HuffmanLasLoader.{h,cpp}. `first_batch`/`num_batches` select a contiguous shard
+    (multi-GPU); the reference always loads the whole file."""
+
+    BATCHES_PER_TASK = 100        # HuffmanLasLoader.cpp:106
+
+    def __init__(self):
+        super().__init__()
+        self.path = ""
+        self.file: Optional[HuffmanFile] = None
+        self.numBatches = self.numPoints = 0
+        self.numBatchesLoaded = self.numPointsLoaded = 0
+        self.first_batch = 0
+        self._next = 0
+
+    @staticmethod
+    def create(path_or_bytes, first_batch: int = 0, num_batches: Optional[int] = None) -> "HuffmanLasData":
+        d = HuffmanLasData()
+        d.path = path_or_bytes if isinstance(path_or_bytes, (str, os.PathLike)) else "<memory>"
+        d.file = HuffmanFile(path_or_bytes)                          # loadHeader()
+        d.first_batch = first_batch
+        d.numBatches = d.file.numBatches - first_batch if num_batches is None else num_batches
+        d.numPoints = d.numBatches * POINTS_PER_BATCH
+        return d
+
+    def load(self, renderer: Renderer):
+        if self.state != Resource.UNLOADED:                          # HuffmanLasLoader.cpp:25-31
+            return
+        self.state = Resource.LOADING
+        hdr = self.file.header(self.first_batch, self.numBatches)
+        renderer.ctx.stream_begin(hdr, self.first_batch)
+        self._next = 0
+        self.numBatchesLoaded = self.numPointsLoaded = 0
+
+    def process(self, renderer: Renderer):
+        """Upload the next task of <= 100 batches (HuffmanLasLoader.cpp:301-313; the reference's reader
+        thread hands them over one task per frame — here the file is already mapped)."""
+        if self.state not in (Resource.LOADING,):
+            return
+        end = min(self.numBatches, self._next + self.BATCHES_PER_TASK)
+        for i in range(self._next, end):
+            renderer.ctx.upload_batch(i, self.file.blob(self.first_batch + i))
+        self._next = end
+        self.numBatchesLoaded = renderer.ctx.batches_loaded
+        self.numPointsLoaded = renderer.ctx.points_loaded
+        if self._next == self.numBatches:
+            nxt = self.first_batch + self.numBatches
+            if nxt < self.file.numBatches:                            # shard boundary: carry the follower's head words
+                renderer.ctx.upload_tail(*self.file.head_words(nxt))
+            self.state = Resource.LOADED
+
+    def load_all(self, renderer: Renderer):
+        self.load(renderer)
+        while self.state == Resource.LOADING:
+            self.process(renderer)
+
+    def unload(self, renderer: Renderer):
+        self.numBatchesLoaded = 0
+        renderer.ctx.stream_unload()
+        self.state = Resource.UNLOADED
+
+
+class _HuffmanMethod(Method):
+    group = "none"
+
+    def __init__(self, renderer: Renderer, las: HuffmanLasData):
+        self.renderer, self.las = renderer, las
+
+    def update(self, renderer: Renderer):                            # huffman_hqs.h:116-124
+        if Runtime.resource is not self.las:
+            if Runtime.resource is not None:
+                Runtime.resource.unload(renderer)
+            self.las.load(renderer)
+            Runtime.resource = self.las
+
+
+class HuffmanMemIter(_HuffmanMethod):
+    """modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h:122-254: decode + {depth,BC1 colour} atomicMin."""
+    name = "huffman_mem_iter_cuda"
+    description = "- Decodes Huffman Encoded values on the GPU"
+
+    def render(self, renderer: Renderer):
+        """One frame. The reference clears at the END of render() for the next frame (:250-252); headless
+        callers want to read the result, so the clear happens at the START of the next frame instead."""
+        self.las.process(renderer)
+        if self.las.numPointsLoaded == 0:
+            return
+        p = renderer.render_params()
+        ctx = renderer.ctx
+        ctx.clear()                   # CLEAR (of the previous frame)
+        ctx.render_basic(p)           # RENDER
+        ctx.resolve_basic(p)          # RESOLVE
+        self.last_params = p
+
+
+class HuffmanHQS(_HuffmanMethod):
+    """modules/huffman_hqs/huffman_hqs.h:126-273: depth pass, 1 % colour accumulation pass, averaging resolve."""
+    name = "huffman_hqs"
+    description = "- Decodes Huffman Encoded values on the GPU"
+
+    def render(self, renderer: Renderer):
+        self.las.process(renderer)
+        if self.las.numPointsLoaded == 0:
+            return
+        p = renderer.render_params()
+        ctx = renderer.ctx
+        ctx.clear()
+        ctx.render_hqs_depth(p)
+        ctx.render_hqs_color(p)
+        ctx.resolve_hqs(p)
+        self.last_params = p

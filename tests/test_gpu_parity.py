@@ -1,0 +1,179 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact, on seeded inputs."""
+import numpy as np
+import pytest
+
+import pcrhpg24_amd as P
+from tests import oracle, scenes
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 360
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    r = P.Renderer(W, H, device=0)
+    yield r
+    r.ctx.close()
+
+
+@pytest.fixture(scope="module")
+def stream200k():
+    """4 batches; every batch huge on screen (double path, 64 points per chain)."""
+    nb, st = scenes.synth_stream(200_000)
+    return nb, oracle.OracleFile(nb.view())
+
+
+@pytest.fixture(scope="module")
+def stream2m():
+    """31 batches: mixes float/double paths, LOD 6..64 points per chain, culled and straddling batches."""
+    nb, st = scenes.synth_stream(2_000_000)
+    return nb, oracle.OracleFile(nb.view())
+
+
+def _load(renderer, nb):
+    P.Runtime.reset()
+    las = P.HuffmanLasData.create(nb)
+    if renderer.ctx.batches_loaded:
+        renderer.ctx.stream_unload()
+    las.load_all(renderer)
+    return las
+
+
+def _check_basic(ctx, of, p):
+    ctx.clear()
+    ctx.render_basic(p)
+    ctx.resolve_basic(p)
+    fb = ctx.read_framebuffer(full=True)
+    ofb, ost = of.render_basic(p)
+    assert ctx.stats() == ost
+    diff = np.nonzero(fb != ofb)[0]
+    assert diff.size == 0, f"{diff.size} framebuffer words differ, first at {diff[:5]}: gpu {fb[diff[:3]]} oracle {ofb[diff[:3]]}"
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(p, ofb))
+    return ost
+
+
+def _check_hqs(ctx, of, p):
+    ctx.clear()
+    ctx.render_hqs_depth(p)
+    st_gpu = ctx.stats()
+    fb = ctx.read_framebuffer(full=True)
+    ofb, ost = of.render_hqs_depth(p)
+    assert st_gpu == ost
+    assert np.array_equal(fb, ofb)
+    ctx.render_hqs_color(p)
+    ctx.resolve_hqs(p)
+    rg, ba = ctx.read_accum(full=True)
+    org, oba, _ = of.render_hqs_color(p, ofb)
+    assert np.array_equal(rg, org) and np.array_equal(ba, oba)
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_hqs(p, ofb, org, oba))
+    return ost
+
+
+@pytest.mark.parametrize("cam", ["overview", "closeup", "inside", "far"])
+@pytest.mark.parametrize("lod,cull", [(10, 1), (100, 0), (100, 1), (37, 1)])
+def test_basic_matches_oracle(renderer, stream2m, cam, lod, cull):
+    nb, of = stream2m
+    _load(renderer, nb)
+    p = scenes.with_flags(scenes.cameras(W, H)[cam], lod_percent=lod, cull=cull)
+    st = _check_basic(renderer.ctx, of, p)
+    assert st["batches_total"] == of.num_batches
+
+
+@pytest.mark.parametrize("cam", ["overview", "closeup", "inside", "far"])
+@pytest.mark.parametrize("lod", [10, 100])
+def test_hqs_matches_oracle(renderer, stream2m, cam, lod):
+    nb, of = stream2m
+    _load(renderer, nb)
+    p = scenes.with_flags(scenes.cameras(W, H)[cam], lod_percent=lod)
+    _check_hqs(renderer.ctx, of, p)
+
+
+@pytest.mark.parametrize("flag", ["show_num_points", "colorize_chunks"])
+def test_small_stream_all_double(renderer, stream200k):
+    nb, of = stream200k
+    _load(renderer, nb)
+    for cam in ("overview", "closeup"):
+        p = scenes.with_flags(scenes.cameras(W, H)[cam], lod_percent=10)
+        _check_basic(renderer.ctx, of, p)
+        _check_hqs(renderer.ctx, of, p)
+
+
+@pytest.mark.parametrize("flag", ["show_num_points", "colorize_chunks"])
+def test_debug_payload_modes(renderer, stream2m, flag):
+    nb, of = stream2m
+    _load(renderer, nb)
+    p = scenes.with_flags(scenes.cameras(W, H)["closeup"], **{flag: 1})
+    _check_hqs(renderer.ctx, of, p)
+    _check_basic(renderer.ctx, of, p)
+
+
+def test_random_escape_heavy_stream(renderer):
+    """Unstructured points: ~every symbol escapes, large int32 deltas, negative coordinates."""
+    x, y, z, c, las = scenes.random_points(150_000, seed=7)
+    nb, st = P.encode_points(x, y, z, c, las, morton_sort=True, nthreads=2)
+    assert st["escaped_symbols"] > 0.3 * st["total_symbols"]
+    of = oracle.OracleFile(nb.view())
+    _load(renderer, nb)
+    for tgt, rad in (((100.0, 100.0, 100.0), 3000.0), ((100.0, 100.0, 100.0), 300.0)):
+        p = scenes.with_flags(P.camera_orbit(0.3, -0.7, rad, tgt, W, H), lod_percent=100)
+        _check_basic(renderer.ctx, of, p)
+        _check_hqs(renderer.ctx, of, p)
+
+
+def test_method_plugins_render_like_reference_session(stream200k):
+    """Drive the path the way main.cpp does: Runtime.addMethod, update(), render() per frame."""
+    nb, of = stream200k
+    P.Runtime.reset()
+    r = P.Renderer(W, H)
+    try:
+        las = P.HuffmanLasData.create(nb)
+        P.Runtime.addMethod(P.HuffmanMemIter(r, las))
+        P.Runtime.addMethod(P.HuffmanHQS(r, las))
+        r.set_camera(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0))
+        for name in ("huffman_mem_iter_cuda", "huffman_hqs"):
+            P.Runtime.setSelectedMethod(name)
+            m = P.Runtime.getSelectedMethod()
+            m.update(r)
+            for _ in range(3):          # progressive loading: <= 100 batches per frame
+                m.render(r)
+            assert las.numBatchesLoaded == of.num_batches
+            p = m.last_params
+            fb = r.ctx.read_framebuffer(full=True)
+            if name == "huffman_hqs":
+                ofb, _ = of.render_hqs_depth(p)
+                org, oba, _ = of.render_hqs_color(p, ofb)
+                assert np.array_equal(fb, ofb)
+                assert np.array_equal(r.ctx.read_rgba(), oracle.resolve_hqs(p, ofb, org, oba))
+            else:
+                ofb, _ = of.render_basic(p)
+                assert np.array_equal(fb, ofb)
+                assert np.array_equal(r.ctx.read_rgba(), oracle.resolve_basic(p, ofb))
+    finally:
+        r.ctx.close()
+        P.Runtime.reset()
+
+
+def test_error_behaviour(renderer, stream200k):
+    nb, _ = stream200k
+    ctx = renderer.ctx
+    f = P.HuffmanFile(nb)
+    if ctx.batches_loaded:
+        ctx.stream_unload()
+    p = scenes.cameras(W, H)["overview"]
+    with pytest.raises(P.PcrError, match="no stream"):
+        ctx.render_basic(p)
+    ctx.stream_begin(f.header())
+    with pytest.raises(P.PcrError, match="in order"):
+        ctx.upload_batch(1, f.blob(1))
+    with pytest.raises(P.PcrError, match="too short|does not match"):
+        ctx.upload_batch(0, bytes(f.blob(0))[:-8])
+    bad = bytearray(f.blob(0))
+    bad[8:12] = (512).to_bytes(4, "little")           # num_threads
+    with pytest.raises(P.PcrError, match="geometry"):
+        ctx.upload_batch(0, bytes(bad))
+    q = p.copy(); q.width = 13
+    ctx.upload_batch(0, f.blob(0))
+    with pytest.raises(P.PcrError, match="image size"):
+        ctx.render_basic(q)
+    ctx.stream_unload()
