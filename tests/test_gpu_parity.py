@@ -89,7 +89,6 @@ def test_hqs_matches_oracle(renderer, stream2m, cam, lod):
     _check_hqs(renderer.ctx, of, p)
 
 
-@pytest.mark.parametrize("flag", ["show_num_points", "colorize_chunks"])
 def test_small_stream_all_double(renderer, stream200k):
     nb, of = stream200k
     _load(renderer, nb)

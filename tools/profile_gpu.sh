@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the default bench workload.
+# Usage: tools/profile_gpu.sh <tag> [bench args...]     outputs under gpurun_out/prof_<tag>/
+set -o pipefail
+TAG=${1:-r01}; shift
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="$PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $BENCH > "$OUT/stats.log" 2>&1 || { tail -20 "$OUT/stats.log"; exit 1; }
+i=0
+for PMC in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+           "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_REQ_sum" \
+           "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc$i" -- python3 $BENCH > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i ($PMC) failed"; tail -5 "$OUT/pmc$i.log"; }
+done
+cd - > /dev/null
+python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
