@@ -40,6 +40,8 @@ extern "C" {
  * 4*1024 bytes (modules/compute/HuffmanLasLoader.cpp:39-41) and SeparateData with nothing. */
 #define PCR_ENCODED_PAD_WORDS     1024
 #define PCR_SEPARATE_PAD_WORDS    256
+/* Zero words kept behind each pad that no upload ever writes: device loads clamp their index into them. */
+#define PCR_GUARD_WORDS           8
 
 #define PCR_BACKGROUND_COLOR      0x00443322u /* resolve.cu:166 */
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 
-HIP_LIB = os.path.join(PKG_DIR, "libpcr_hip.so")
+HIP_LIB = os.environ.get("PCR_HIP_LIB") or os.path.join(PKG_DIR, "libpcr_hip.so")   # override: experiment builds
 HOST_LIB = os.path.join(PKG_DIR, "libpcr_host.so")
 
 # -ffp-contract=off is part of the numeric contract: FMAs are spelled out in the sources.

@@ -221,7 +221,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
     c->sep_words = h->separate_bytes / 4 + PCR_SEPARATE_PAD_WORDS;
     int rc;
     if ((rc = dalloc_zero(c, c->d_batches, nB)) || (rc = dalloc_zero(c, c->d_start, nB * 3072)) ||
-        (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words)) || (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words)) ||
+        (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS)) || (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words + PCR_GUARD_WORDS)) ||
         (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096)) ||
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32)) ||
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB))) {

@@ -139,18 +139,36 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// BC1 (render.cu:23-65), always 4-colour mode
+// decode + rasterize: one workgroup per batch, 16 wave64 = 32 stream clusters
+//
+// Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
+//   s_table  16 KiB  decoder table packed to one dword per key: value<<6 | wide<<5 | escape<<4 | len
+//                    (a table value that does not fit 26 bits is flagged `wide` and re-read from global memory)
+//   s_ring   32 KiB  per cluster a 256-word ring of its word stream, filled 128 words at a time by coalesced
+//                    16-byte-per-lane loads issued one chunk (~6 points) ahead and staged in registers, so the
+//                    per-symbol refill is an LDS read instead of a dependent global load
+//   s_esc    28 KiB  per wave the escape ("separate") words of its 64 chains, bulk-loaded coalesced up front
+//                    (waves whose chains hold more than ESC_WORDS escapes read them from global memory instead)
+// Every global load left in the loop is issued at the END of an iteration and consumed at the end of a later
+// one: the framebuffer pre-read of point i is tested after point i+1 has been decoded, the next stream chunk
+// is written to the ring one chunk later, the BC1 block of the chain's next 16 points 16 iterations later.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t decode_bc1(uint32_t point_index, const uint8_t *colors)
+constexpr int CHUNK_WORDS = 128;                // per cluster and staging load: 32 lanes x 4 words
+constexpr int RING_WORDS  = 2 * CHUNK_WORDS;    // per cluster
+#ifndef PCR_ESC_WORDS
+#define PCR_ESC_WORDS 448
+#endif
+constexpr int ESC_WORDS   = PCR_ESC_WORDS;      // per wave
+constexpr uint32_t TE_LEN = 15u, TE_ESCAPE = 16u, TE_WIDE = 32u;   // packed table entry fields (value in bits 31:6)
+
+__device__ __forceinline__ uint32_t bc1_from_block(uint2 blk, uint32_t local)
 {
-    const uint2 blk = *reinterpret_cast<const uint2 *>(colors + (size_t)(point_index >> 4) * 8);
-    const uint32_t local = point_index & 15u;
     const uint32_t l = blk.x & 0xFFFFu, h = blk.x >> 16;
     const int cr0 = (l >> 11) & 31, cg0 = (l >> 5) & 63, cb0 = l & 31;
     const int r0 = (cr0 << 3) | (cr0 >> 2), g0 = (cg0 << 2) | (cg0 >> 4), b0 = (cb0 << 3) | (cb0 >> 2);
     const int cr1 = (h >> 11) & 31, cg1 = (h >> 5) & 63, cb1 = h & 31;
     const int r1 = (cr1 << 3) | (cr1 >> 2), g1 = (cg1 << 2) | (cg1 >> 4), b1 = (cb1 << 3) | (cb1 >> 2);
-    const uint32_t sel = (blk.y >> (2 * local)) & 3u;   // byte 4 + local/4, bits 2*(local%4)
+    const uint32_t sel = (blk.y >> (2 * local)) & 3u;   // byte 4 + local/4, bits 2*(local%4): render.cu:48
     int r, g, b;
     if (sel == 0)      { r = r0; g = g0; b = b0; }
     else if (sel == 1) { r = r1; g = g1; b = b1; }
@@ -159,54 +177,34 @@ __device__ __forceinline__ uint32_t decode_bc1(uint32_t point_index, const uint8
     return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
 }
 
-// ------------------------------------------------------------------------------------------------
-// project + scatter one point (render.cu:276-303; hqs depth.cu:127-154; hqs render.cu:274-316)
-// ------------------------------------------------------------------------------------------------
+// Second half of rasterize() (render.cu:297-301 / depth.cu:148-151 / hqs render.cu:292-313) for a point whose
+// framebuffer word `old` was loaded one iteration earlier. A stale `old` only makes the filter less selective:
+// framebuffer words never increase during a pass, and the atomic decides.
 template <int MODE>
-__device__ __forceinline__ void rasterize(const RenderArgs &a, float x, float y, float z,
-                                          uint32_t local_point_index, uint32_t payload)
+__device__ __forceinline__ void scatter(const RenderArgs &a, uint32_t pix, uint32_t depth, uint64_t old,
+                                        uint2 cblk, uint32_t local, uint32_t payload)
 {
-    const float *M = a.p.transform;
-    const float px = dot4(M + 0, x, y, z, 1.0f);
-    const float py = dot4(M + 4, x, y, z, 1.0f);
-    const float pw = dot4(M + 12, x, y, z, 1.0f);
-    const float nx = px / pw, ny = py / pw;
-    // inside test (:296), NaN-rejecting form
-    if (!(pw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f)) return;
-    const float ix = __fmaf_rn(nx, 0.5f, 0.5f) * (float)a.p.width;   // :283
-    const float iy = __fmaf_rn(ny, 0.5f, 0.5f) * (float)a.p.height;
-    const uint32_t pix = (uint32_t)((int)ix + (int)iy * a.p.width);  // :284-285
-    if (pix >= a.f.fb_elems) return;
-    const uint32_t depth = __float_as_uint(pw);                      // :287
-
     if (MODE == MODE_HQS_COLOR) {
-        const uint64_t old = a.f.fb[pix];
+        const float pw = __uint_as_float(depth);
         const float old_depth = __uint_as_float((uint32_t)(old >> 32));
         if ((double)pw <= (double)old_depth * 1.01) {                // hqs render.cu:296
-            const uint32_t rgba = decode_bc1(local_point_index, a.s.colors);
+            const uint32_t rgba = bc1_from_block(cblk, local);
             const uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
             atomicAdd((unsigned long long *)&a.f.rg[pix], (unsigned long long)((r << 32) | g));    // :309-310
             atomicAdd((unsigned long long *)&a.f.ba[pix], (unsigned long long)((b << 32) | 1u));   // :311-312
         }
     } else if (MODE == MODE_BASIC) {
-        // Pre-read filter (:297-298) on the depth half only, so the result is exactly
-        // min(depth<<32|colour) over all inside points (Appendix C.5).
-        const uint64_t hi = (uint64_t)depth << 32;
-        const uint64_t old = a.f.fb[pix];
-        if (hi <= (old | 0xFFFFFFFFull)) {
-            const uint64_t key = hi | decode_bc1(local_point_index, a.s.colors);                   // :299
+        // pre-read filter (:297-298) on the depth half only: result == min(depth<<32|colour) over all inside points
+        if (depth <= (uint32_t)(old >> 32)) {
+            const uint64_t key = ((uint64_t)depth << 32) | bc1_from_block(cblk, local);            // :299
             if (key < old) atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key); // :300
         }
     } else {
         const uint64_t key = ((uint64_t)depth << 32) | payload;                                    // depth.cu:139-145
-        const uint64_t old = a.f.fb[pix];
         if (key < old) atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);     // :148-151
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// decode + rasterize: one workgroup per batch
-// ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
 {
@@ -217,40 +215,73 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
     const bool use_double = (lod & LOD_DOUBLE) != 0;
     const uint32_t tid = threadIdx.x;
 
-    // decoder table -> LDS as {value, len} pairs so one ds_read_b64 serves a symbol (render.cu:383-395)
-    __shared__ int2 s_table[PCR_HUFFMAN_TABLE_SIZE];
+    __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
+    __shared__ __align__(16) uint32_t s_ring[PCR_CLUSTERS_PER_BATCH * RING_WORDS];
+    __shared__ int32_t s_esc[(PCR_WORKGROUP_SIZE / 64) * ESC_WORDS];
+
+    // decoder table -> LDS (render.cu:383-395), four entries per thread
+    const int32_t *tvalues = a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE;
     {
-        const int4 v = reinterpret_cast<const int4 *>(a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+        const int4 v = reinterpret_cast<const int4 *>(tvalues)[tid];
         const uint32_t l4 = reinterpret_cast<const uint32_t *>(a.s.table_lens + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
-        s_table[tid * 4 + 0] = make_int2(v.x, (int)(int8_t)(l4 & 0xFF));
-        s_table[tid * 4 + 1] = make_int2(v.y, (int)(int8_t)((l4 >> 8) & 0xFF));
-        s_table[tid * 4 + 2] = make_int2(v.z, (int)(int8_t)((l4 >> 16) & 0xFF));
-        s_table[tid * 4 + 3] = make_int2(v.w, (int)(int8_t)(l4 >> 24));
+        auto pack = [](int32_t value, uint32_t lbyte) -> uint32_t {
+            const int len = (int)(int8_t)lbyte;                             // render.cu:393 narrows to char
+            const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE : 0u);
+            if (len <= 0) return f;                                         // escapes never use the table value
+            return ((int32_t)((uint32_t)value << 6) >> 6) == value ? (((uint32_t)value << 6) | f) : (f | TE_WIDE);
+        };
+        uint4 e;
+        e.x = pack(v.x, l4 & 0xFF); e.y = pack(v.y, (l4 >> 8) & 0xFF);
+        e.z = pack(v.z, (l4 >> 16) & 0xFF); e.w = pack(v.w, l4 >> 24);
+        reinterpret_cast<uint4 *>(s_table)[tid] = e;
     }
 
     const pcr_gpu_batch *gb = a.s.batches + b;
     const int64_t enc_off = gb->encoding_batch_offset;      // :404
     const int64_t sep_off = gb->separate_batch_offset;      // :405
-    const uint32_t *enc = a.s.encoded + enc_off;            // batch-relative base (uniform)
+    const uint32_t *enc = a.s.encoded + enc_off;            // batch-relative bases (uniform)
     const int32_t *sep = a.s.separate + sep_off;
-    // reads past the allocation (zero pad included) are defined as 0
-    const uint32_t enc_limit = (uint32_t)min((int64_t)0x7FFFFFFF, a.s.encoded_words - enc_off);
-    const uint32_t sep_limit = (uint32_t)min((int64_t)0x7FFFFFFF, a.s.separate_words - sep_off);
+    // Reads past the logical end of a stream (zero pad included) are defined as 0. The allocations carry
+    // PCR_GUARD_WORDS extra zero words that nothing ever writes, so clamping the index to the guard is enough:
+    // branch-free loads keep every global load of the loop on one control-flow path (no conservative waits).
+    const uint32_t enc_last = (uint32_t)min((int64_t)0x7FFFFFF0, a.s.encoded_words + (PCR_GUARD_WORDS - 4) - enc_off);
+    const uint32_t sep_last = (uint32_t)min((int64_t)0x7FFFFFF0, a.s.separate_words + (PCR_GUARD_WORDS - 2) - sep_off);
+    auto enc_load = [&](uint32_t i) -> uint32_t { return enc[min(i, enc_last)]; };
+    auto sep_load = [&](uint32_t i) -> int32_t { return sep[min(i, sep_last)]; };
+    auto enc_load4 = [&](uint32_t i) -> uint4 {             // four consecutive stream words, 4-byte aligned
+        uint4 v;
+        __builtin_memcpy(&v, enc + min(i, enc_last), 16);
+        return v;
+    };
 
+    const uint32_t wave = tid >> 6;
     const uint32_t cluster = tid >> 5;                      // 32-lane cluster of the stream format
     const uint32_t lane32 = tid & 31u;
     const uint32_t half_shift = tid & 32u;                  // which half of the wave64 ballot is mine
     const uint32_t lanes_below = (1u << lane32) - 1u;       // (CUDA's mask << (32 - tid), without the shift-by-32)
 
-    uint32_t ep = cluster ? (uint32_t)a.s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;    // :407-410
-    uint32_t sp = tid ? (uint32_t)a.s.separate_sizes[(size_t)b * 1024 + tid - 1] : 0u;         // :411-413
-    auto enc_load = [&](uint32_t i) -> uint32_t { return i < enc_limit ? enc[i] : 0u; };
-    auto sep_load = [&](uint32_t i) -> int32_t { return i < sep_limit ? sep[i] : 0; };
+    // ---- escape words of this wave's 64 chains -> LDS -----------------------------------------------------
+    const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
+    const uint32_t esc_first = wave ? (uint32_t)ssz[wave * 64 - 1] : 0u;        // wave-uniform
+    const uint32_t esc_count = (uint32_t)ssz[wave * 64 + 63] - esc_first;
+    // words of the wave's range held in LDS: all of them, or none (escape-heavy wave: read from global memory)
+    const uint32_t esc_lds = esc_count <= (uint32_t)ESC_WORDS ? esc_count : 0u;
+    int32_t *esc = s_esc + wave * ESC_WORDS;
+    for (uint32_t i = tid & 63u; i < esc_lds; i += 64) esc[i] = sep_load(esc_first + i);
+    uint32_t sp = (tid ? (uint32_t)ssz[tid - 1] : 0u) - esc_first;              // :411-413, relative to the wave's range
 
-    uint32_t cur = enc_load(ep + lane32);                   // :416
-    uint32_t nxt = enc_load(ep + 32 + lane32);              // :417
-    ep += 64;                                               // == EncodedPtr + already_read (:418)
+    // ---- word stream of my cluster: words 0..63 straight to registers, chunks 0,1 to the ring, chunk 2 staged
+    const uint32_t cbase = cluster ? (uint32_t)a.s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;   // :407-410
+    uint32_t *ring = s_ring + cluster * RING_WORDS;
+    uint32_t cur = enc_load(cbase + lane32);                // :416
+    uint32_t nxt = enc_load(cbase + 32 + lane32);           // :417
+    reinterpret_cast<uint4 *>(ring)[lane32] = enc_load4(cbase + lane32 * 4);
+    reinterpret_cast<uint4 *>(ring + CHUNK_WORDS)[lane32] = enc_load4(cbase + CHUNK_WORDS + lane32 * 4);
+    uint4 stage = enc_load4(cbase + 2 * CHUNK_WORDS + lane32 * 4);
+    uint32_t ep = 64;                                       // already_read (:418): next stream word of the cluster
+    uint32_t next_cross = CHUNK_WORDS;                      // ep value at which the ring's older chunk is dead
     int cur_bits = 32;                                      // :419
+
     const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + tid) * 3;   // :421-424
     int32_t px = sv[0], py = sv[1], pz = sv[2];
 
@@ -264,9 +295,29 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
         if (a.p.show_num_points)      payload = (uint32_t)npr;                                   // depth.cu:139-140
         else if (a.p.colorize_chunks) payload = (uint32_t)(a.s.batch_index_base + b);            // :141-142
     }
-    const uint32_t point_base = b * PCR_POINTS_PER_BATCH + tid * PCR_POINTS_PER_THREAD;          // :453
 
-    __syncthreads();
+    // BC1 blocks of my chain: 4 blocks x 8 bytes = 32 contiguous bytes per lane, all loaded up front
+    // (coalesced 16-byte loads; first use is hundreds of cycles away)
+    uint4 c01 = make_uint4(0, 0, 0, 0), c23 = make_uint4(0, 0, 0, 0);
+    if (MODE != MODE_HQS_DEPTH) {
+        const uint4 *cblocks = reinterpret_cast<const uint4 *>(a.s.colors) + ((size_t)b * 2048 + tid * 2);
+        c01 = cblocks[0];
+        c23 = cblocks[1];
+    }
+    auto color_block = [&](int point) -> uint2 {            // block of in-chain point index (wave-uniform)
+        const uint32_t lo01 = (point & 16) ? c01.z : c01.x, hi01 = (point & 16) ? c01.w : c01.y;
+        const uint32_t lo23 = (point & 16) ? c23.z : c23.x, hi23 = (point & 16) ? c23.w : c23.y;
+        return make_uint2((point & 32) ? lo23 : lo01, (point & 32) ? hi23 : hi01);
+    };
+
+    // deferred scatter of the previous point
+    uint32_t pend_pix = 0xFFFFFFFFu, pend_depth = 0;
+    uint64_t pend_old = 0;
+
+    const float *M = a.p.transform;
+    const float fw = (float)a.p.width, fh = (float)a.p.height;
+
+    __syncthreads();        // table, ring and escape windows are visible
 
     for (int i = 0; i < npr; ++i) {                                         // :428
         int32_t dec[3];
@@ -275,23 +326,41 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
             // 12-bit window at the read position: == ((L|R) & mask) >> 20 of :431-433
             const uint64_t w = ((uint64_t)cur << 32) | nxt;
             const uint32_t key = (uint32_t)(w >> (20 + cur_bits)) & 0xFFFu;
-            const int2 e = s_table[key];                                    // :435-436
-            int32_t val = e.x;
-            const int len = e.y;
-            if (len <= 0) { val = sep_load(sp); ++sp; }                     // :438
-            cur_bits -= abs(len);                                           // :439
+            const uint32_t e = s_table[key];                                // :435-436
+            int32_t val = (int32_t)e >> 6;
+            if (e & (TE_ESCAPE | TE_WIDE)) {
+                if (e & TE_ESCAPE) {                                        // :438
+                    if (sp < esc_lds) {
+                        val = esc[sp];
+                    } else {
+                        // outside the LDS window (escape-heavy wave, or a tail over-read past the wave's own
+                        // range): the load is consumed inside this branch so no pending VMEM result leaves it
+                        val = sep_load(esc_first + sp);
+                        asm volatile("; escape word from global memory %0" : "+v"(val));
+                    }
+                    ++sp;
+                } else {
+                    val = tvalues[key];
+                    asm volatile("; wide table value from global memory %0" : "+v"(val));
+                }
+            }
+            cur_bits -= (int)(e & TE_LEN);                                  // :439
             const bool need = cur_bits <= 0;                                // :442
             const uint64_t m = __ballot(need);                              // :443
             const uint32_t mh = (uint32_t)(m >> half_shift);
             if (need) {                                                     // :444-449
                 cur = nxt;
-                nxt = enc_load(ep + __popc(mh & lanes_below));
+                nxt = ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
                 cur_bits += 32;
             }
             ep += __popc(mh);                                               // :450
             dec[j] = val;
         }
         px += dec[0]; py += dec[1]; pz += dec[2];                           // :454-456, :463
+#ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
+        if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
+        continue;
+#endif
         float x, y, z;
         if (use_double) {                                                   // :459-461
             x = (float)__fma_rn((double)px, sx, ox);
@@ -302,8 +371,49 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
             y = __fmaf_rn((float)py, fsy, foy);
             z = __fmaf_rn((float)pz, fsz, foz);
         }
-        rasterize<MODE>(a, x, y, z, point_base + (uint32_t)i, payload);     // :465
+
+        // first half of rasterize() (:278-287) for point i
+        const float qx = dot4(M + 0, x, y, z, 1.0f);
+        const float qy = dot4(M + 4, x, y, z, 1.0f);
+        const float qw = dot4(M + 12, x, y, z, 1.0f);
+        const float nx = qx / qw, ny = qy / qw;
+        uint32_t pix = 0xFFFFFFFFu;
+        // inside test (:296), NaN-rejecting form
+        if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {
+            const float ix = __fmaf_rn(nx, 0.5f, 0.5f) * fw;                // :283
+            const float iy = __fmaf_rn(ny, 0.5f, 0.5f) * fh;
+            pix = (uint32_t)((int)ix + (int)iy * a.p.width);                // :284-285
+            if (pix >= a.f.fb_elems) pix = 0xFFFFFFFFu;
+        }
+
+        // second half for point i-1, whose framebuffer word has been in flight since the previous iteration
+        if (pend_pix != 0xFFFFFFFFu)
+            scatter<MODE>(a, pend_pix, pend_depth, pend_old, color_block(i - 1), (uint32_t)(i - 1) & 15u, payload);
+        if (ep >= next_cross) {
+            // My half of the wave has consumed the ring's older chunk (at most 96 words go per iteration, so one
+            // check per point keeps every refill inside the two resident chunks): overwrite it with the staged
+            // chunk and fetch the chunk after that. Wave-internal LDS traffic: DS operations of a wave execute
+            // in order, the fences below only stop the compiler from reordering.
+            reinterpret_cast<uint4 *>(ring + ((next_cross + CHUNK_WORDS) & (RING_WORDS - 1)))[lane32] = stage;
+            stage = enc_load4(cbase + next_cross + 2 * CHUNK_WORDS + lane32 * 4);
+            next_cross += CHUNK_WORDS;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pend_pix = pix;
+        pend_depth = __float_as_uint(qw);                                   // :287
+#if defined(PCR_EXP_NO_FBLOAD)     /* experiment only: projection math without the framebuffer traffic (results are wrong) */
+        if (pix == 0x12345678u) a.f.fb[tid] = pend_depth;
+        pend_pix = 0xFFFFFFFFu;
+#elif defined(PCR_EXP_COALESCED_FB) /* experiment only: framebuffer pre-read at lane-consecutive addresses */
+        if (pix != 0xFFFFFFFFu) pend_old = a.f.fb[(pix & 0xFFFC0u) + (tid & 63u)];
+#else
+        if (pix != 0xFFFFFFFFu) pend_old = a.f.fb[pix];                     // :297, consumed next iteration
+#endif
     }
+    if (pend_pix != 0xFFFFFFFFu)
+        scatter<MODE>(a, pend_pix, pend_depth, pend_old, color_block(npr - 1), (uint32_t)(npr - 1) & 15u, payload);
 }
 
 // ------------------------------------------------------------------------------------------------
