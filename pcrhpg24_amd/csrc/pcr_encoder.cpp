@@ -49,13 +49,15 @@ inline MortonKey morton_key(uint32_t X, uint32_t Y, uint32_t Z)
     MortonKey k;
     k.lo = spread3_21(X) | (spread3_21(Y) << 1) | (spread3_21(Z) << 2);     // mymorton.h:16-20
     k.lo |= (uint64_t)((X >> 21) & 1u) << 63;                                // :23
-    uint32_t hi = ((Y >> 21) & 1u) | (((Z >> 21) & 1u) << 1);                // :26-27
+    // The reference accumulates these in 64-bit arithmetic and stores them into a uint32_t (mymorton.h:10,30-34):
+    // bit 31 of X would land on bit 32 and is dropped by that truncation. Reproduced, not fixed.
+    uint64_t hi = ((Y >> 21) & 1u) | (((Z >> 21) & 1u) << 1);                // :26-27
     for (int i = 22; i < 32; ++i) {                                          // :30-34
-        hi |= ((X >> i) & 1u) << (3 * (i - 21) + 2);
-        hi |= ((Y >> i) & 1u) << (3 * (i - 21) + 0);
-        hi |= ((Z >> i) & 1u) << (3 * (i - 21) + 1);
+        hi |= (uint64_t)((X >> i) & 1u) << (3 * (i - 21) + 2);
+        hi |= (uint64_t)((Y >> i) & 1u) << (3 * (i - 21) + 0);
+        hi |= (uint64_t)((Z >> i) & 1u) << (3 * (i - 21) + 1);
     }
-    k.hi = hi;
+    k.hi = (uint32_t)hi;
     return k;
 }
 

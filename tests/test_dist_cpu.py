@@ -1,0 +1,94 @@
+"""Multi-process (gloo, world_size 2) tests of the sharding + framebuffer-merge layer on CPU.
+Each rank renders its contiguous batch range with the oracle (standing in for a GPU), merges through
+pcrhpg24_amd.dist, and every rank must end with the single-process result, bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pcrhpg24_amd as P
+from pcrhpg24_amd import dist as pdist
+from tests import oracle, scenes
+
+W, H = 320, 180
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        image, _ = P.synth_encode(total, scenes.SEED, nthreads=2)
+        of = oracle.OracleFile(image.view())
+        first, count = pdist.shard_range(of.num_batches, world, rank)
+        cam = scenes.with_flags(scenes.cameras(W, H)["overview"], lod_percent=100)
+        # basic: shard render -> min merge
+        fb, _ = of.render_basic(cam, first=first, count=count)
+        pdist.allreduce_min_u64_numpy(fb)
+        # HQS: depth -> min merge -> colour against the GLOBAL depth -> sum merge
+        d, _ = of.render_hqs_depth(cam, first=first, count=count)
+        pdist.allreduce_min_u64_numpy(d)
+        rg, ba, _ = of.render_hqs_color(cam, d, first=first, count=count)
+        pdist.allreduce_sum_u64_numpy(rg); pdist.allreduce_sum_u64_numpy(ba)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fb=fb, d=d, rg=rg, ba=ba)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 31, 1526, 30518):
+        for w in (1, 2, 3, 8):
+            r = [pdist.shard_range(n, w, k) for k in range(w)]
+            assert r[0][0] == 0 and sum(c for _, c in r) == n
+            assert all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(c for _, c in r) - min(c for _, c in r) <= 1
+
+
+def test_two_ranks_reproduce_single_process_render(tmp_path):
+    total = 600_000                         # 10 batches -> 5 + 5
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    image, _ = P.synth_encode(total, scenes.SEED, nthreads=2)
+    of = oracle.OracleFile(image.view())
+    cam = scenes.with_flags(scenes.cameras(W, H)["overview"], lod_percent=100)
+    fb, _ = of.render_basic(cam)
+    d, _ = of.render_hqs_depth(cam)
+    rg, ba, _ = of.render_hqs_color(cam, d)
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert np.array_equal(z["fb"], fb), "merged basic framebuffer differs from the single-process render"
+        assert np.array_equal(z["d"], d) and np.array_equal(z["rg"], rg) and np.array_equal(z["ba"], ba)
+
+
+def test_shard_upload_view_equals_the_global_stream_segment():
+    """What a rank uploads for batches [first, first+count) + the follower's head words is byte-identical to the
+    same window of the single-stream layout, so tail over-reads see the same words on any rank."""
+    image, _ = scenes.synth_stream(600_000)
+    f = P.HuffmanFile(image)
+    of = oracle.OracleFile(image.view())
+    e, s = of.encoded(), of.separate()
+    first, count = pdist.shard_range(f.numBatches, 2, 0)
+    hdr = f.header(first, count)
+    g0, g1 = of.batch(first), of.batch(first + count)
+    assert hdr.encoded_bytes == 4 * (g1.encoding_batch_offset - g0.encoding_batch_offset)
+    assert hdr.separate_bytes == 4 * (g1.separate_batch_offset - g0.separate_batch_offset)
+    he, hs = f.head_words(first + count)
+    assert np.array_equal(he, e[g1.encoding_batch_offset:g1.encoding_batch_offset + len(he)])
+    assert np.array_equal(hs, s[g1.separate_batch_offset:g1.separate_batch_offset + len(hs)])
+    assert len(he) == 1024 and len(hs) <= 256
+
+
+def test_sign_flip_min_is_unsigned_min():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 2 ** 64, 1000, dtype=np.uint64); b = rng.integers(0, 2 ** 64, 1000, dtype=np.uint64)
+    a[:10] = 0xFFFFFFFFFFFFFFFF
+    fa, fb = (a ^ pdist.SIGN).view(np.int64), (b ^ pdist.SIGN).view(np.int64)
+    assert np.array_equal(np.minimum(fa, fb).view(np.uint64) ^ pdist.SIGN, np.minimum(a, b))
