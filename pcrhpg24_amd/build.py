@@ -61,9 +61,29 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+RENDER_BIN = os.path.join(PKG_DIR, "pcr_render")
+PREPROCESS_BIN = os.path.join(PKG_DIR, "pcr_preprocess")
+
+
+def build_tools(force: bool = False) -> None:
+    """C++ host adapters (csrc/pcr_methods.hpp) as headless executables: pcr_render (the reference's main.cpp flow)
+    and pcr_preprocess (the reference's preprocess CLI)."""
+    build_host(force)
+    build_hip(force)
+    rsrc = [os.path.join(CSRC, "pcr_render.cpp"), os.path.join(CSRC, "pcr_methods.hpp"), HIP_LIB, HOST_LIB]
+    if force or _stale(RENDER_BIN, rsrc):
+        _run([_hipcc(), "-O2", "-std=c++17", "-I", INCLUDE, "-I", CSRC, rsrc[0], "-o", RENDER_BIN,
+              "-L", PKG_DIR, "-lpcr_hip", "-lpcr_host", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+    psrc = [os.path.join(CSRC, "pcr_preprocess.cpp"), HOST_LIB]
+    if force or _stale(PREPROCESS_BIN, psrc):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INCLUDE, psrc[0], "-o", PREPROCESS_BIN,
+              "-L", PKG_DIR, "-lpcr_host", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+
+
 def build_all(force: bool = False) -> None:
     build_host(force)
     build_hip(force)
+    build_tools(force)
 
 
 if __name__ == "__main__":

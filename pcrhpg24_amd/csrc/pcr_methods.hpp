@@ -1,0 +1,277 @@
+// pcr_methods.hpp — C++ host-side adapters with the reference's plugin surface, over the C ABI (pcr_hip.h).
+//
+// A maintainer of the reference swaps the CUDA-driver bodies of these classes for the pcr_* calls below; the
+// names, members and call order are the reference's:
+//   Method / Runtime / Debug              include/Method.h:10-23, include/Runtime.h:15-55, include/Debug.h:14-31
+//   Resource, HuffmanLasData              modules/compute/Resources.h:20-35, modules/compute/HuffmanLasLoader.{h,cpp}
+//   HuffmanMemIter ("huffman_mem_iter_cuda")   modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h
+//   HuffmanHQS     ("huffman_hqs")              modules/huffman_hqs/huffman_hqs.h
+// Headless: `Renderer` carries the window size and the orbit camera only (no GLFW/GL/ImGui); the resolve target is
+// a device RGBA8 buffer instead of a GL texture.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pcr_encode.h"
+#include "pcr_hip.h"
+
+namespace pcr_host {
+
+struct Debug {                                  // include/Debug.h:21-30 (flags the Huffman methods read)
+    inline static float LOD = 0.1f;
+    inline static bool frustumCullingEnabled = true;
+    inline static bool colorizeChunks = false;
+    inline static bool showNumPoints = false;
+};
+
+struct Renderer {
+    int width = 1920, height = 1080;            // src/Renderer.cpp:142-143
+    pcr_ctx *ctx = nullptr;
+    double yaw = 0, pitch = 0, radius = 10, target[3] = {0, 0, 0};   // include/OrbitControls.h
+
+    explicit Renderer(int w = 1920, int h = 1080, int device = 0) : width(w), height(h)
+    {
+        if (pcr_create(device, &ctx) != PCR_OK) throw std::runtime_error(std::string("pcr_create: ") + pcr_last_error(nullptr));
+        check(pcr_set_image_size(ctx, w, h), "pcr_set_image_size");
+    }
+    ~Renderer() { pcr_destroy(ctx); }
+    Renderer(const Renderer &) = delete;
+
+    void check(int rc, const char *what) const
+    {
+        if (rc != PCR_OK) throw std::runtime_error(std::string(what) + ": " + pcr_last_error(ctx));
+    }
+
+    // ChangingRenderData as HuffmanHQS::render fills it (huffman_hqs.h:157-183)
+    pcr_render_params params() const
+    {
+        pcr_render_params p;
+        if (pcr_camera_orbit(yaw, pitch, radius, target, width, height, 60.0, 0.1, 200000.0, &p))
+            throw std::runtime_error(std::string("pcr_camera_orbit: ") + pcr_host_last_error());
+        p.lod_percent = (int)(Debug::LOD * 100);
+        p.enable_frustum_culling = Debug::frustumCullingEnabled;
+        p.colorize_chunks = Debug::colorizeChunks;
+        p.show_num_points = Debug::showNumPoints;
+        return p;
+    }
+};
+
+enum ResourceState { UNLOADED, LOADING, LOADED, UNLOADING };   // Resources.h:20-25
+
+struct Resource {
+    ResourceState state = UNLOADED;
+    virtual ~Resource() = default;
+    virtual void load(Renderer *renderer) = 0;
+    virtual void unload(Renderer *renderer) = 0;
+    virtual void process(Renderer *renderer) = 0;
+};
+
+struct Method {
+    std::string name = "no name", description = "", group = "no group";
+    virtual ~Method() = default;
+    virtual void update(Renderer *renderer) = 0;
+    virtual void render(Renderer *renderer) = 0;
+};
+
+struct Runtime {
+    inline static std::vector<Method *> methods;
+    inline static Method *selectedMethod = nullptr;
+    inline static Resource *resource = nullptr;
+    static void addMethod(Method *m) { methods.push_back(m); }
+    static void setSelectedMethod(const std::string &name)
+    {
+        for (Method *m : methods) if (m->name == name) selectedMethod = m;
+    }
+    static Method *getSelectedMethod() { return selectedMethod; }
+};
+
+// modules/compute/HuffmanLasLoader.{h,cpp}: header parse, progressive loading through a reader thread that hands
+// over tasks of <= 100 batch records (cpp:81-149), uploadBatch on the render thread (cpp:176-313).
+struct HuffmanLasData : Resource {
+    struct LoaderTask {
+        std::vector<std::vector<char>> buffers;
+        std::vector<int64_t> batchIndices;
+    };
+
+    std::string path;
+    int64_t numBatches = 0, numPoints = 0, encodedBytes = 0, separateBytes = 0, clusterBytes = 0;
+    std::vector<int64_t> batch_data_sizes, batch_data_sizes_prefix;
+    int64_t numBatchesLoaded = 0, numPointsLoaded = 0, offsetToBatchData = 0;
+
+    std::shared_ptr<LoaderTask> task;
+    std::mutex mtx_state, mtx_tasks;
+    std::thread reader;
+
+    ~HuffmanLasData() override { stopReader(); }
+
+    void loadHeader()                                       // HuffmanLasLoader.h:57-85
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open " + path);
+        int64_t h[5];
+        f.read((char *)h, sizeof h);
+        if (!f) throw std::runtime_error(path + ": shorter than its header");
+        numPoints = h[0]; numBatches = h[1]; encodedBytes = h[2]; separateBytes = h[3]; clusterBytes = h[4];
+        if (numBatches <= 0 || numPoints != numBatches * PCR_POINTS_PER_BATCH) throw std::runtime_error(path + ": bad header");
+        batch_data_sizes.resize((size_t)numBatches);
+        f.read((char *)batch_data_sizes.data(), 8 * numBatches);
+        if (!f) throw std::runtime_error(path + ": shorter than its batch size table");
+        batch_data_sizes_prefix = batch_data_sizes;
+        for (int64_t i = 1; i < numBatches; ++i) batch_data_sizes_prefix[(size_t)i] += batch_data_sizes_prefix[(size_t)i - 1];
+        offsetToBatchData = 40 + 8 * numBatches;
+    }
+
+    static std::shared_ptr<HuffmanLasData> create(const std::string &path)   // HuffmanLasLoader.h:87-92
+    {
+        auto d = std::make_shared<HuffmanLasData>();
+        d->path = path;
+        d->loadHeader();
+        return d;
+    }
+
+    void load(Renderer *renderer) override                  // HuffmanLasLoader.cpp:22-150
+    {
+        {
+            std::lock_guard<std::mutex> lock(mtx_state);
+            if (state != UNLOADED) return;
+            state = LOADING;
+        }
+        pcr_file_header hdr{numPoints, numBatches, encodedBytes, separateBytes, clusterBytes};
+        renderer->check(pcr_stream_begin(renderer->ctx, &hdr, 0), "pcr_stream_begin");
+        numBatchesLoaded = numPointsLoaded = 0;
+        reader = std::thread([this] {
+            std::ifstream f(path, std::ios::binary);
+            int64_t remaining = numBatches, read = 0;
+            while (remaining > 0) {
+                {
+                    std::lock_guard<std::mutex> lock(mtx_state);
+                    if (state == UNLOADING) { state = UNLOADED; return; }
+                }
+                {
+                    std::lock_guard<std::mutex> lock(mtx_tasks);
+                    if (task) { std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }
+                }
+                auto t = std::make_shared<LoaderTask>();
+                int64_t n = remaining < 100 ? remaining : 100;
+                for (int64_t i = 0; i < n; ++i) {
+                    int64_t b = read + i;
+                    int64_t start = offsetToBatchData + (b ? batch_data_sizes_prefix[(size_t)b - 1] : 0);
+                    std::vector<char> buf((size_t)batch_data_sizes[(size_t)b]);
+                    f.seekg(start);
+                    f.read(buf.data(), (std::streamsize)buf.size());
+                    t->buffers.push_back(std::move(buf));
+                    t->batchIndices.push_back(b);
+                }
+                read += n; remaining -= n;
+                std::lock_guard<std::mutex> lock(mtx_tasks);
+                task = t;
+            }
+            std::lock_guard<std::mutex> lock(mtx_state);
+            if (state == UNLOADING) state = UNLOADED;
+            else if (state == LOADING) state = LOADED;
+        });
+    }
+
+    void process(Renderer *renderer) override               // HuffmanLasLoader.cpp:301-313
+    {
+        std::lock_guard<std::mutex> lock(mtx_tasks);
+        if (!task) return;
+        for (size_t i = 0; i < task->batchIndices.size(); ++i) {
+            renderer->check(pcr_upload_batch(renderer->ctx, task->batchIndices[i], task->buffers[i].data(), task->buffers[i].size()),
+                            "pcr_upload_batch");
+        }
+        numBatchesLoaded = pcr_batches_loaded(renderer->ctx);
+        numPointsLoaded = pcr_points_loaded(renderer->ctx);
+        task = nullptr;
+    }
+
+    void unload(Renderer *renderer) override                // HuffmanLasLoader.cpp:152-174
+    {
+        stopReader();
+        numBatchesLoaded = 0;
+        pcr_stream_unload(renderer->ctx);
+        std::lock_guard<std::mutex> lock(mtx_state);
+        state = UNLOADED;
+    }
+
+    bool fullyLoaded() const { return numBatchesLoaded == numBatches; }
+
+private:
+    void stopReader()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mtx_state);
+            if (state == LOADING) state = UNLOADING;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mtx_tasks);
+            task = nullptr;
+        }
+        if (reader.joinable()) reader.join();
+    }
+};
+
+struct HuffmanMethodBase : Method {
+    std::shared_ptr<HuffmanLasData> las;
+    Renderer *renderer;
+    pcr_render_params lastParams{};
+    HuffmanMethodBase(Renderer *r, std::shared_ptr<HuffmanLasData> l) : las(std::move(l)), renderer(r) { group = "none"; }
+
+    void update(Renderer *r) override                      // huffman_hqs.h:116-124
+    {
+        if (Runtime::resource != (Resource *)las.get()) {
+            if (Runtime::resource != nullptr) Runtime::resource->unload(r);
+            las->load(r);
+            Runtime::resource = (Resource *)las.get();
+        }
+    }
+};
+
+// One frame = CLEAR (of the previous frame) + RENDER + RESOLVE. The reference clears at the end of render()
+// (huffman_mem_iter_cuda.h:250-252); headless callers read the result, so the clear opens the next frame instead.
+struct HuffmanMemIter : HuffmanMethodBase {
+    HuffmanMemIter(Renderer *r, std::shared_ptr<HuffmanLasData> l) : HuffmanMethodBase(r, std::move(l))
+    {
+        name = "huffman_mem_iter_cuda";
+        description = "- Decodes Huffman Encoded values on the GPU";
+    }
+    void render(Renderer *r) override                      // huffman_mem_iter_cuda.h:122-254
+    {
+        las->process(r);
+        if (las->numPointsLoaded == 0) return;
+        lastParams = r->params();
+        r->check(pcr_clear(r->ctx), "pcr_clear");
+        r->check(pcr_render_basic(r->ctx, &lastParams), "pcr_render_basic");
+        r->check(pcr_resolve_basic(r->ctx, &lastParams), "pcr_resolve_basic");
+    }
+};
+
+struct HuffmanHQS : HuffmanMethodBase {
+    HuffmanHQS(Renderer *r, std::shared_ptr<HuffmanLasData> l) : HuffmanMethodBase(r, std::move(l))
+    {
+        name = "huffman_hqs";
+        description = "- Decodes Huffman Encoded values on the GPU";
+    }
+    void render(Renderer *r) override                      // huffman_hqs.h:126-273
+    {
+        las->process(r);
+        if (las->numPointsLoaded == 0) return;
+        lastParams = r->params();
+        r->check(pcr_clear(r->ctx), "pcr_clear");
+        r->check(pcr_render_hqs_depth(r->ctx, &lastParams), "pcr_render_hqs_depth");
+        r->check(pcr_render_hqs_color(r->ctx, &lastParams), "pcr_render_hqs_color");
+        r->check(pcr_resolve_hqs(r->ctx, &lastParams), "pcr_resolve_hqs");
+    }
+};
+
+} // namespace pcr_host

@@ -1,0 +1,85 @@
+"""The C++ host adapters as executables: pcr_preprocess (reference: `preprocess in.las out.huffman sort`,
+src/preprocess.cpp:1167-1279) and pcr_render (reference: src/main.cpp flow through Method/Resource)."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import pcrhpg24_amd as P
+from pcrhpg24_amd import build
+from tests import oracle, scenes
+
+
+def write_las(path, x, y, z, r, g, b, scale=(0.001, 0.001, 0.001), offset=(10.0, 20.0, 30.0)):
+    """Minimal LAS 1.2, point format 2 (26-byte records): what LasLoader::loadSync reads (preprocess.cpp:74-171)."""
+    n = len(x)
+    hdr = bytearray(227)
+    hdr[0:4] = b"LASF"
+    hdr[24], hdr[25] = 1, 2
+    struct.pack_into("<H", hdr, 94, 227)
+    struct.pack_into("<I", hdr, 96, 227)
+    hdr[104] = 2
+    struct.pack_into("<H", hdr, 105, 26)
+    struct.pack_into("<I", hdr, 107, n)
+    struct.pack_into("<3d", hdr, 131, *scale)
+    struct.pack_into("<3d", hdr, 155, *offset)
+    wx, wy, wz = x * scale[0] + offset[0], y * scale[1] + offset[1], z * scale[2] + offset[2]
+    struct.pack_into("<6d", hdr, 179, wx.max(), wx.min(), wy.max(), wy.min(), wz.max(), wz.min())
+    rec = np.zeros(n, dtype=[("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("pad", "V8"), ("r", "<u2"), ("g", "<u2"), ("b", "<u2")])
+    rec["x"], rec["y"], rec["z"], rec["r"], rec["g"], rec["b"] = x, y, z, r, g, b
+    assert rec.itemsize == 26
+    with open(path, "wb") as f:
+        f.write(hdr); f.write(rec.tobytes())
+    las = P.LasInfo()
+    for k, (lo, hi) in enumerate(((wx.min(), wx.max()), (wy.min(), wy.max()), (wz.min(), wz.max()))):
+        las.scale[k], las.offset[k], las.min[k], las.max[k] = scale[k], offset[k], lo, hi
+    return las
+
+
+def test_preprocess_cli_equals_library_encoder(tmp_path):
+    build.build_tools()
+    rng = np.random.default_rng(2)
+    n = 70_000
+    x = rng.integers(0, 400000, n).astype(np.int32); y = rng.integers(0, 300000, n).astype(np.int32)
+    z = (1000 * np.sin(x / 40000.0) + rng.integers(-20, 20, n)).astype(np.int32)
+    r = rng.integers(0, 65536, n).astype(np.uint16); g = rng.integers(0, 256, n).astype(np.uint16); b = rng.integers(0, 65536, n).astype(np.uint16)
+    las = write_las(tmp_path / "in.las", x, y, z, r, g, b)
+    out = tmp_path / "out.huffman"
+    res = subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "in.las"), str(out), "1", "2"], stdout=subprocess.PIPE, text=True)
+    assert res.returncode == 0 and "batches 2" in res.stdout
+    conv = lambda v: np.where(v > 255, v // 256, v).astype(np.uint32)          # preprocess.cpp:150-152
+    color = conv(r) | (conv(g) << 8) | (conv(b) << 16)
+    image, st = P.encode_points(x, y, z, color, las, morton_sort=True, nthreads=2)
+    assert out.read_bytes() == bytes(image.view())
+    of = oracle.OracleFile(out.read_bytes())
+    g0 = of.batch(0)
+    assert (g0.scale_x, g0.offset_y) == (0.001, 20.0)
+    assert abs(g0.las_min_x - (x.min() * 0.001 + 10.0)) < 1e-3
+    assert subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "nope.las"), str(out), "1"], stderr=subprocess.PIPE).returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["huffman_mem_iter_cuda", "huffman_hqs"])
+def test_render_cli_matches_oracle(tmp_path, method):
+    build.build_tools()
+    image, _ = scenes.synth_stream(2_000_000)
+    path = tmp_path / "scene.huffman"
+    path.write_bytes(bytes(image.view()))
+    W, H = 640, 360
+    cam = ["-0.15", "-0.57", "1500", "500", "500", "40"]
+    res = subprocess.run([build.RENDER_BIN, str(path), "--method", method, "--size", f"{W}x{H}", "--camera", *cam,
+                          "--lod", "0.1", "--dump-fb", str(tmp_path / "fb.u64"), "--dump-rgba", str(tmp_path / "o.ppm")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["method"] == method and info["batches"] == 31
+    fb = np.fromfile(tmp_path / "fb.u64", np.uint64)
+    of = oracle.OracleFile(image.view())
+    p = P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), W, H)     # Debug::LOD 0.1, culling on
+    ofb, ost = (of.render_basic(p) if method == "huffman_mem_iter_cuda" else of.render_hqs_depth(p))
+    assert np.array_equal(fb, ofb[:W * H])
+    assert info["points_iterated"] == ost["points_iterated"] and info["covered_pixels"] == int((ofb[:W * H] != 2 ** 64 - 1).sum())
+    assert (tmp_path / "o.ppm").stat().st_size > W * H * 3
