@@ -39,6 +39,7 @@ struct pcr_ctx {
     int32_t *d_cluster_sizes = nullptr;
     uint8_t *d_colors = nullptr;
     uint32_t *d_lod = nullptr;
+    uint2 *d_win = nullptr;
     pcr_render_stats *d_stats = nullptr;
     std::vector<int8_t> lens_scratch;
 
@@ -76,7 +77,7 @@ template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; }
 void free_stream_buffers(pcr_ctx *c)
 {
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
-    dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod);
+    dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
@@ -119,7 +120,7 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.s.encoded_words = c->enc_words; a.s.separate_words = c->sep_words;
     a.s.num_batches = c->batches_loaded; a.s.batch_index_base = c->batch_index_base;
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
-    a.lod = c->d_lod; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
+    a.lod = c->d_lod; a.win = c->d_win; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
     return a;
 }
 
@@ -224,7 +225,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS)) || (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words + PCR_GUARD_WORDS)) ||
         (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096)) ||
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32)) ||
-        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB))) {
+        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB)) || (rc = dalloc_zero(c, c->d_win, nB))) {
         free_stream_buffers(c);
         return rc;
     }
