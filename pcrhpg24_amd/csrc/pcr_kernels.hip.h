@@ -206,6 +206,7 @@ __device__ __forceinline__ uint32_t bc1_from_block(uint2 blk, uint32_t local)
 }
 
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int MODE>
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
@@ -420,14 +421,34 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
         const float qx = dot4(M + 0, x, y, z, 1.0f);
         const float qy = dot4(M + 4, x, y, z, 1.0f);
         const float qw = dot4(M + 12, x, y, z, 1.0f);
-        const float nx = qx / qw, ny = qy / qw;
         uint32_t pix = NO_PIXEL, widx = NO_PIXEL;
-        // inside test (:296), NaN-rejecting form
-        if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {
-            const int ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);           // :283-284
-            const int iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
-            pix = (uint32_t)(ix + iy * a.p.width);                          // :285
-            if (pix >= a.f.fb_elems) pix = NO_PIXEL;
+        // Inside test (:296) without dividing: for finite w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1]
+        // exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w > 1 + 2^-24, which rounds above 1). The division
+        // itself is the IEEE sequence hipcc emits for `/` with its range scaling removed, shared reciprocal, x and y
+        // packed; it is bit-identical to `/` for w in [2^-64, 2^64) (no intermediate leaves the normal range unless
+        // |x/w| < 2^-36, where the pixel is the screen centre whatever the last bits are). Anything else takes `/`.
+        const bool w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;        // 2^-64 <= w < 2^64
+        if (__builtin_expect(__any(!w_ok && !(qw <= 0.0f)), 0)) {
+            const float nx = qx / qw, ny = qy / qw;
+            if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {   // NaN-rejecting (Appendix C.2)
+                const int ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);       // :283-284
+                const int iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+                pix = (uint32_t)(ix + iy * a.p.width);                      // :285
+                if (pix >= a.f.fb_elems) pix = NO_PIXEL;
+                const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
+                if (rx < ww && ry < wh) widx = ry * ww + rx;
+            }
+        } else if (w_ok && fabsf(qx) <= qw && fabsf(qy) <= qw) {
+            const float r0 = __builtin_amdgcn_rcpf(qw);
+            const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
+            const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
+            const v2f q0 = xy * rr;
+            const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
+            const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
+            const v2f half = {0.5f, 0.5f}, size = {fw, fh};
+            const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
+            const int ix = (int)img.x, iy = (int)img.y;                             // :284
+            pix = (uint32_t)(ix + iy * a.p.width);                                  // :285 (always < fb_elems here)
             const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
             if (rx < ww && ry < wh) widx = ry * ww + rx;
         }
