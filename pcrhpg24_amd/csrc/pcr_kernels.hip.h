@@ -29,6 +29,7 @@ enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2 };
 constexpr int CHUNK_WORDS    = 64;               // stream staging granule per cluster: 32 lanes x 2 words (8-byte loads)
 constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                                   -> 16 KiB
 constexpr int ESC_POOL_WORDS = 6144;             // escape words of the whole batch, pooled        -> 24 KiB
+constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
 constexpr int WIN_PIXELS     = 2560;             // u64 framebuffer window of the batch's rectangle -> 20 KiB
 constexpr uint32_t TE_LEN = 15u, TE_ESCAPE = 16u, TE_WIDE = 32u;   // packed table entry fields (value in bits 31:6)
 
@@ -189,27 +190,38 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
 //                    one per new per-pixel minimum (6.9 -> ~1.5 per covered pixel on the benchmark frame).
 // Global loads left in the loop are consumed at least one iteration after they are issued.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t bc1_from_block(uint2 blk, uint32_t local)
+// BC1 block -> its four palette colours as 0x00BBGGRR (render.cu:31-62, always 4-colour mode)
+struct Bc1Palette { uint32_t c0, c1, c2, c3, selectors; };
+
+__device__ __forceinline__ Bc1Palette bc1_palette(uint2 blk)
 {
     const uint32_t l = blk.x & 0xFFFFu, h = blk.x >> 16;
     const int cr0 = (l >> 11) & 31, cg0 = (l >> 5) & 63, cb0 = l & 31;
     const int r0 = (cr0 << 3) | (cr0 >> 2), g0 = (cg0 << 2) | (cg0 >> 4), b0 = (cb0 << 3) | (cb0 >> 2);
     const int cr1 = (h >> 11) & 31, cg1 = (h >> 5) & 63, cb1 = h & 31;
     const int r1 = (cr1 << 3) | (cr1 >> 2), g1 = (cg1 << 2) | (cg1 >> 4), b1 = (cb1 << 3) | (cb1 >> 2);
-    const uint32_t sel = (blk.y >> (2 * local)) & 3u;   // byte 4 + local/4, bits 2*(local%4): render.cu:48
-    int r, g, b;
-    if (sel == 0)      { r = r0; g = g0; b = b0; }
-    else if (sel == 1) { r = r1; g = g1; b = b1; }
-    else if (sel == 2) { r = (r0 * 2 + r1) / 3; g = (g0 * 2 + g1) / 3; b = (b0 * 2 + b1) / 3; }
-    else               { r = (r0 + r1 * 2) / 3; g = (g0 + g1 * 2) / 3; b = (b0 + b1 * 2) / 3; }
-    return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+    auto rgb = [](int r, int g, int b) { return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16); };
+    Bc1Palette p;
+    p.c0 = rgb(r0, g0, b0);
+    p.c1 = rgb(r1, g1, b1);
+    p.c2 = rgb((r0 * 2 + r1) / 3, (g0 * 2 + g1) / 3, (b0 * 2 + b1) / 3);
+    p.c3 = rgb((r0 + r1 * 2) / 3, (g0 + g1 * 2) / 3, (b0 + b1 * 2) / 3);
+    p.selectors = blk.y;                                    // byte 4 + local/4, bits 2*(local%4): render.cu:48
+    return p;
+}
+
+__device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t local)
+{
+    const uint32_t sel = (p.selectors >> (2 * local)) & 3u;
+    const uint32_t lo = (sel & 1u) ? p.c1 : p.c0, hi = (sel & 1u) ? p.c3 : p.c2;
+    return (sel & 2u) ? hi : lo;
 }
 
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int MODE>
-__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two workgroups per CU -> <= 64 VGPRs
 {
     const uint32_t b = blockIdx.x;
     const uint32_t lod = a.lod[b];
@@ -266,8 +278,18 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
     // ---- escape words of the batch -> LDS (all of them, or none) --------------------------------------------
     const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
     const uint32_t esc_total = (uint32_t)ssz[1023];
-    const uint32_t esc_lds = esc_total <= (uint32_t)ESC_POOL_WORDS ? esc_total : 0u;
-    for (uint32_t i = tid; i < esc_lds; i += PCR_WORKGROUP_SIZE) s_esc[i] = sep_load(i);
+    // The pool also takes ESC_SLACK words that FOLLOW the batch's own escapes in memory, so that the reference's
+    // tail over-reads find in LDS what they would find in global memory; reads beyond even that, and
+    // batches that do not fit, go to global memory (slow variant of the decode step).
+    const uint32_t esc_lds = esc_total + ESC_SLACK <= (uint32_t)ESC_POOL_WORDS ? esc_total + ESC_SLACK : 0u;
+    {   // all loads of a thread in flight together (ESC_POOL_WORDS / 1024 = 6 per thread)
+        int32_t v[ESC_POOL_WORDS / PCR_WORKGROUP_SIZE];
+#pragma unroll
+        for (int k = 0; k < ESC_POOL_WORDS / PCR_WORKGROUP_SIZE; ++k) v[k] = sep_load(tid + k * PCR_WORKGROUP_SIZE);
+#pragma unroll
+        for (int k = 0; k < ESC_POOL_WORDS / PCR_WORKGROUP_SIZE; ++k)
+            if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = v[k];
+    }
     uint32_t sp = tid ? (uint32_t)ssz[tid - 1] : 0u;        // :411-413 (batch-relative)
 
     // ---- framebuffer window of the batch's rectangle -> LDS --------------------------------------------------
@@ -275,9 +297,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
     const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
     const uint32_t wpix = ww * wh;                          // 0: no window for this batch
     const uint32_t W = (uint32_t)a.p.width;
-    for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
-        const uint32_t y = i / ww, x = i - y * ww;
-        s_win[i] = a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];  // a stale snapshot is a valid (conservative) start
+    {   // snapshot of the rectangle, all loads of a thread in flight together (a stale value is a valid start)
+        unsigned long long v[(WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE];
+#pragma unroll
+        for (int k = 0; k < (WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE; ++k) {
+            const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
+            const uint32_t y = i / max(ww, 1u), x = i - y * ww;
+            v[k] = i < wpix ? a.f.fb[(size_t)(wy0 + y) * W + wx0 + x] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < (WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE; ++k) {
+            const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
+            if (i < wpix) s_win[i] = v[k];
+        }
     }
 
     // ---- word stream of my cluster: words 0..63 straight to registers, chunks 1,2 to the ring, chunk 3 staged
@@ -306,19 +338,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
         else if (a.p.colorize_chunks) payload = (uint32_t)(a.s.batch_index_base + b);            // :141-142
     }
 
-    // BC1 blocks of my chain: 4 blocks x 8 bytes = 32 contiguous bytes per lane, all loaded up front
-    // (coalesced 16-byte loads; first use is hundreds of cycles away)
-    uint4 c01 = make_uint4(0, 0, 0, 0), c23 = make_uint4(0, 0, 0, 0);
-    if (MODE != MODE_HQS_DEPTH) {
-        const uint4 *cblocks = reinterpret_cast<const uint4 *>(a.s.colors) + ((size_t)b * 2048 + tid * 2);
-        c01 = cblocks[0];
-        c23 = cblocks[1];
-    }
-    auto color_block = [&](int point) -> uint2 {            // block of in-chain point index (wave-uniform)
-        const uint32_t lo01 = (point & 16) ? c01.z : c01.x, hi01 = (point & 16) ? c01.w : c01.y;
-        const uint32_t lo23 = (point & 16) ? c23.z : c23.x, hi23 = (point & 16) ? c23.w : c23.y;
-        return make_uint2((point & 32) ? lo23 : lo01, (point & 32) ? hi23 : hi01);
-    };
+    // BC1 blocks of my chain (4 blocks of 16 points, 8 bytes each): the block of the current 16-point segment in
+    // registers, the next one prefetched a whole segment (16 iterations) before its first use
+    const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors) + ((size_t)b * 4096 + tid * 4);
+    Bc1Palette pal = {0, 0, 0, 0, 0};
+    uint2 cnext = make_uint2(0, 0);
+    if (MODE != MODE_HQS_DEPTH) cnext = cblocks[0];
 
     // Second half of rasterize() (render.cu:297-301 / depth.cu:148-151 / hqs render.cu:292-313) for the point whose
     // framebuffer word `old` was fetched one iteration earlier, from the LDS window (widx) or from global memory.
@@ -328,7 +353,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
             const float pw = __uint_as_float(depth);
             const float old_depth = __uint_as_float((uint32_t)(old >> 32));
             if ((double)pw <= (double)old_depth * 1.01) {                   // hqs render.cu:296
-                const uint32_t rgba = bc1_from_block(color_block(point), (uint32_t)point & 15u);
+                const uint32_t rgba = bc1_color(pal, (uint32_t)point & 15u);
                 const uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, bl = (rgba >> 16) & 255u;
                 atomicAdd((unsigned long long *)&a.f.rg[pix], (unsigned long long)((r << 32) | g));    // :309-310
                 atomicAdd((unsigned long long *)&a.f.ba[pix], (unsigned long long)((bl << 32) | 1u));  // :311-312
@@ -339,7 +364,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
         if (MODE == MODE_BASIC) {
             // pre-read filter (:297-298) on the depth half only: result == min(depth<<32|colour) over all inside points
             if (depth > (uint32_t)(old >> 32)) return;
-            key = ((uint64_t)depth << 32) | bc1_from_block(color_block(point), (uint32_t)point & 15u);   // :299
+            key = ((uint64_t)depth << 32) | bc1_color(pal, (uint32_t)point & 15u);   // :299
         } else {
             key = ((uint64_t)depth << 32) | payload;                        // depth.cu:139-145
         }
@@ -356,56 +381,71 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
 
     __syncthreads();        // table, ring, escapes and window are visible
 
-    for (int i = 0; i < npr; ++i) {                                         // :428
+    for (int seg = 0; seg < npr; seg += 16) {
+      // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
+      // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
+      if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, seg - 1);
+      pend_pix = NO_PIXEL;
+      if (MODE != MODE_HQS_DEPTH) {
+          pal = bc1_palette(cnext);                     // once per 16 points instead of once per surviving point
+          cnext = cblocks[min((seg >> 4) + 1, 3)];
+      }
+      const int seg_end = min(seg + 16, npr);
+#pragma unroll 1
+      for (int i = seg; i < seg_end; ++i) {                                 // :428
         int32_t dec[3];
+        {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {                                       // :430
-            // 12-bit window at the read position: == ((L|R) & mask) >> 20 of :431-433
-            const uint64_t w = ((uint64_t)cur << 32) | nxt;
-            const uint32_t key = (uint32_t)(w >> (20 + cur_bits)) & 0xFFFu;
-            const uint32_t e = s_table[key];                                // :435-436
-            int32_t val = (int32_t)e >> 6;
-            if (e & (TE_ESCAPE | TE_WIDE)) {
-                if (e & TE_ESCAPE) {                                        // :438
-                    if (sp < esc_lds) {
-                        val = s_esc[sp];
+            for (int j = 0; j < 3; ++j) {                                   // :430
+                const uint64_t w = ((uint64_t)cur << 32) | nxt;
+                const uint32_t key = (uint32_t)(w >> (20 + cur_bits)) & 0xFFFu;
+                const uint32_t e = s_table[key];                            // :435-436
+                int32_t val = (int32_t)e >> 6;
+                if (e & (TE_ESCAPE | TE_WIDE)) {
+                    if (e & TE_ESCAPE) {                                    // :438
+                        if (sp < esc_lds) {
+                            val = s_esc[sp];
+                        } else {
+                            // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
+                            val = sep_load(sp);
+                            asm volatile("; escape word from global memory %0" : "+v"(val));
+                        }
+                        ++sp;
                     } else {
-                        // outside the LDS pool (escape-heavy batch, or a tail over-read past the batch's own range):
-                        // the load is consumed inside this branch so no pending VMEM result leaves it
-                        val = sep_load(sp);
-                        asm volatile("; escape word from global memory %0" : "+v"(val));
+                        val = tvalues[key];
+                        asm volatile("; wide table value from global memory %0" : "+v"(val));
                     }
-                    ++sp;
-                } else {
-                    val = tvalues[key];
-                    asm volatile("; wide table value from global memory %0" : "+v"(val));
                 }
+                cur_bits -= (int)(e & TE_LEN);                              // :439
+                const bool need = cur_bits <= 0;                            // :442
+                const uint64_t m = __ballot(need);                          // :443
+                const uint32_t mh = (uint32_t)(m >> half_shift);
+                if (need) {                                                 // :444-449
+                    cur = nxt;
+                    nxt = ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
+                    cur_bits += 32;
+                }
+                ep += __popc(mh);                                           // :450
+                if (ep >= next_cross) {
+                    // My half of the wave has consumed the ring's older chunk (a step takes at most 32 words, so every
+                    // refill stays inside the two resident chunks): overwrite it with the staged chunk and fetch the
+                    // chunk after that. Wave-internal LDS traffic: DS operations of a wave execute in order, the
+                    // fences below only stop the compiler from reordering.
+                    reinterpret_cast<uint2 *>(ring + ((next_cross + CHUNK_WORDS) & (RING_WORDS - 1)))[lane32] = stage;
+                    stage = enc_load2(cbase + next_cross + 2 * CHUNK_WORDS + lane32 * 2);
+                    next_cross += CHUNK_WORDS;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                dec[j] = val;
             }
-            cur_bits -= (int)(e & TE_LEN);                                  // :439
-            const bool need = cur_bits <= 0;                                // :442
-            const uint64_t m = __ballot(need);                              // :443
-            const uint32_t mh = (uint32_t)(m >> half_shift);
-            if (need) {                                                     // :444-449
-                cur = nxt;
-                nxt = ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
-                cur_bits += 32;
-            }
-            ep += __popc(mh);                                               // :450
-            if (ep >= next_cross) {
-                // My half of the wave has consumed the ring's older chunk (a step takes at most 32 words, so every
-                // refill stays inside the two resident chunks): overwrite it with the staged chunk and fetch the
-                // chunk after that. Wave-internal LDS traffic: DS operations of a wave execute in order, the
-                // fences below only stop the compiler from reordering.
-                reinterpret_cast<uint2 *>(ring + ((next_cross + CHUNK_WORDS) & (RING_WORDS - 1)))[lane32] = stage;
-                stage = enc_load2(cbase + next_cross + 2 * CHUNK_WORDS + lane32 * 2);
-                next_cross += CHUNK_WORDS;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            dec[j] = val;
         }
         px += dec[0]; py += dec[1]; pz += dec[2];                           // :454-456, :463
+#ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
+        if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
+        continue;
+#endif
         float x, y, z;
         if (use_double) {                                                   // :459-461
             x = (float)__fma_rn((double)px, sx, ox);
@@ -453,6 +493,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
             if (rx < ww && ry < wh) widx = ry * ww + rx;
         }
 
+#ifdef PCR_EXP_NO_FBLOAD   /* experiment only: decode + projection, no framebuffer traffic (results are wrong) */
+        if (pix == 0x12345678u || widx == 0x123456u) a.f.fb[tid] = __float_as_uint(qw);
+        continue;
+#endif
         // second half for point i-1, whose framebuffer word has been in flight since the previous iteration
         if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, i - 1);
         pend_pix = pix;
@@ -460,6 +504,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_render(RenderArgs a)
         pend_depth = __float_as_uint(qw);                                   // :287
         if (widx != NO_PIXEL)      pend_old = s_win[widx];                  // :297 on the LDS copy
         else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
+      }
     }
     if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr - 1);
 
