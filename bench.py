@@ -74,8 +74,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PCR_FORCE_DIST=1 exercises the multi-GPU code path (torch-owned framebuffers, shared stream, sign-flip +
+    # RCCL all-reduce) with a single rank, which is all a one-GPU box can run
+    use_dist = world > 1 or os.environ.get("PCR_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nthreads = args.threads or min(os.cpu_count() or 8, 16)
@@ -117,12 +121,12 @@ def main():
     p.lod_percent = args.lod
     p.enable_frustum_culling = args.cull
 
-    frame = pdist.DeviceFrame(ctx, args.width, args.height, dev) if world > 1 else None
+    frame = pdist.DeviceFrame(ctx, args.width, args.height, dev) if use_dist else None
     step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world)) if args.method == "basic" else \
            (lambda: pdist.render_hqs_sharded(ctx, frame, p, world))
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -139,7 +143,7 @@ def main():
     st = ctx.stats()            # counters of the last render launch (per rank)
     pts = torch.tensor([st["points_iterated"]], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     points_per_step = float(pts.item())
@@ -208,7 +212,7 @@ def main():
                        "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
-                       "parallelism": "batch-sharded x%d + RCCL min all-reduce" % world if world > 1 else "single GPU",
+                       "parallelism": "batch-sharded x%d + RCCL min all-reduce" % world if use_dist else "single GPU",
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
@@ -219,7 +223,7 @@ def main():
     if frame is not None:
         frame.release()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -131,6 +131,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const int64_t nB = c->batches_loaded;            // "don't execute a workgroup until all points inside are loaded"
     if (nB == 0) return PCR_OK;                      // huffman_hqs.h:137
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
+    a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
     HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream));
     hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);

@@ -31,6 +31,7 @@ constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                 
 constexpr int ESC_POOL_WORDS = 6144;             // escape words of the whole batch, pooled        -> 24 KiB
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
 constexpr int WIN_PIXELS     = 2560;             // u64 framebuffer window of the batch's rectangle -> 20 KiB
+constexpr int WIN_PIXELS_HQS = 1024;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 20 KiB
 constexpr uint32_t TE_LEN = 15u, TE_ESCAPE = 16u, TE_WIDE = 32u;   // packed table entry fields (value in bits 31:6)
 
 // Device-side view of the loaded stream (own layout; the reference keeps nine flat CuBuffers,
@@ -67,6 +68,7 @@ struct RenderArgs {
     uint2 *win;               // [nB] LDS depth-window rectangle per batch: {x0 | y0<<16, w | h<<16}, w == 0: none
     pcr_render_stats *stats;  // device
     int variant_hqs;          // LOD expression variant
+    int win_capacity;         // pixels the LDS window of the following k_render<MODE> can hold
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
             const int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
             const int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
             const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
-            if (ww > 0 && wh > 0 && ww * wh <= WIN_PIXELS && x0 < 65536 && y0 < 65536)
+            if (ww > 0 && wh > 0 && ww * wh <= a.win_capacity && x0 < 65536 && y0 < 65536)
                 wr = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)ww | ((uint32_t)wh << 16));
         }
     }
@@ -297,6 +299,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
     const uint32_t wpix = ww * wh;                          // 0: no window for this batch
     const uint32_t W = (uint32_t)a.p.width;
+    // colour pass layout of the same 20 KiB: sums in the framebuffer's own packed format + the depth to test against
+    unsigned long long *const s_rg = s_win, *const s_ba = s_win + WIN_PIXELS_HQS;
+    uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * WIN_PIXELS_HQS);
     {   // snapshot of the rectangle, all loads of a thread in flight together (a stale value is a valid start)
         unsigned long long v[(WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE];
 #pragma unroll
@@ -308,7 +313,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #pragma unroll
         for (int k = 0; k < (WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE; ++k) {
             const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
-            if (i < wpix) s_win[i] = v[k];
+            if (i < wpix) {
+                if (MODE == MODE_HQS_COLOR) { s_depth[i] = (uint32_t)(v[k] >> 32); s_rg[i] = 0; s_ba[i] = 0; }
+                else                        s_win[i] = v[k];
+            }
         }
     }
 
@@ -348,6 +356,20 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // Second half of rasterize() (render.cu:297-301 / depth.cu:148-151 / hqs render.cu:292-313) for the point whose
     // framebuffer word `old` was fetched one iteration earlier, from the LDS window (widx) or from global memory.
     // A stale `old` only makes the filter less selective: framebuffer words never increase during a pass.
+    // colour pass: run of contributions to one pixel held in registers
+    uint32_t run_pix = NO_PIXEL, run_widx = NO_PIXEL;
+    unsigned long long run_rg = 0, run_ba = 0;
+    auto flush_run = [&]() {
+        if (run_pix == NO_PIXEL) return;
+        if (run_widx != NO_PIXEL) {
+            // per-batch partial sums in LDS (a batch adds at most 65 536 * 255 < 2^32 per 32-bit half)
+            __hip_atomic_fetch_add(&s_rg[run_widx], run_rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_ba[run_widx], run_ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            atomicAdd((unsigned long long *)&a.f.rg[run_pix], run_rg);      // :309-310
+            atomicAdd((unsigned long long *)&a.f.ba[run_pix], run_ba);      // :311-312
+        }
+    };
     auto scatter = [&](uint32_t pix, uint32_t widx, uint32_t depth, uint64_t old, int point) {
         if (MODE == MODE_HQS_COLOR) {
             const float pw = __uint_as_float(depth);
@@ -355,8 +377,16 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             if ((double)pw <= (double)old_depth * 1.01) {                   // hqs render.cu:296
                 const uint32_t rgba = bc1_color(pal, (uint32_t)point & 15u);
                 const uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, bl = (rgba >> 16) & 255u;
-                atomicAdd((unsigned long long *)&a.f.rg[pix], (unsigned long long)((r << 32) | g));    // :309-310
-                atomicAdd((unsigned long long *)&a.f.ba[pix], (unsigned long long)((bl << 32) | 1u));  // :311-312
+                const unsigned long long vrg = (r << 32) | g, vba = (bl << 32) | 1u;
+                // Consecutive points of a chain are Morton neighbours and mostly land in the same pixel: their
+                // contributions are summed in registers and written once per run (sums commute, so the totals
+                // are unchanged; a chain adds at most 64 * 255 per 32-bit half).
+                if (pix == run_pix) {
+                    run_rg += vrg; run_ba += vba;
+                } else {
+                    flush_run();
+                    run_pix = pix; run_widx = widx; run_rg = vrg; run_ba = vba;
+                }
             }
             return;
         }
@@ -502,21 +532,31 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         pend_pix = pix;
         pend_widx = widx;
         pend_depth = __float_as_uint(qw);                                   // :287
-        if (widx != NO_PIXEL)      pend_old = s_win[widx];                  // :297 on the LDS copy
+        if (widx != NO_PIXEL)      pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[widx] << 32 : s_win[widx];   // :297 on the LDS copy
         else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
       }
     }
     if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr - 1);
+    if (MODE == MODE_HQS_COLOR) flush_run();
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
-    if (MODE != MODE_HQS_COLOR && wpix) {
+    if (wpix) {
         __syncthreads();
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
             const uint32_t y = i / ww, x = i - y * ww;
-            const unsigned long long v = s_win[i];
-            unsigned long long *g = (unsigned long long *)&a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
-            if (v < *g) atomicMin(g, v);
+            const size_t gp = (size_t)(wy0 + y) * W + wx0 + x;
+            if (MODE == MODE_HQS_COLOR) {
+                const unsigned long long vba = s_ba[i];
+                if (vba) {
+                    atomicAdd((unsigned long long *)&a.f.rg[gp], s_rg[i]);
+                    atomicAdd((unsigned long long *)&a.f.ba[gp], vba);
+                }
+            } else {
+                const unsigned long long v = s_win[i];
+                unsigned long long *g = (unsigned long long *)&a.f.fb[gp];
+                if (v < *g) atomicMin(g, v);
+            }
         }
     }
 }

@@ -81,7 +81,7 @@ def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: 
     """One frame of the basic method on this rank's shard + the merge. Enqueue only."""
     ctx.clear()
     ctx.render_basic(params)
-    if world_size > 1:
+    if frame is not None:
         frame.allreduce_min(group)
     ctx.resolve_basic(params)
 
@@ -89,9 +89,9 @@ def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: 
 def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None):
     ctx.clear()
     ctx.render_hqs_depth(params)
-    if world_size > 1:
+    if frame is not None:
         frame.allreduce_min(group)          # global depth before the 1 % test
     ctx.render_hqs_color(params)
-    if world_size > 1:
+    if frame is not None:
         frame.allreduce_sum(group)
     ctx.resolve_hqs(params)
