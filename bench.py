@@ -121,15 +121,26 @@ def main():
     p.lod_percent = args.lod
     p.enable_frustum_culling = args.cull
 
-    frame = pdist.DeviceFrame(ctx, args.width, args.height, dev) if use_dist else None
-    step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world)) if args.method == "basic" else \
-           (lambda: pdist.render_hqs_sharded(ctx, frame, p, world))
+    frame, pipe = None, None
+    if use_dist and args.method == "basic" and os.environ.get("PCR_NO_OVERLAP") != "1":
+        pipe = pdist.PipelinedBasicRenderer(ctx, args.width, args.height, dev)   # merge of frame k overlaps render k+1
+        step = lambda: pipe.step(p)
+    else:
+        if use_dist:
+            frame = pdist.DeviceFrame(ctx, args.width, args.height, dev)
+            frame.bind()
+            ctx.clear()
+        step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world)) if args.method == "basic" else \
+               (lambda: pdist.render_hqs_sharded(ctx, frame, p, world))
 
     def fence():
-        if use_dist:
-            dist.barrier()
+        if pipe is not None:
+            pipe.finish()
         ctx.synchronize()
         torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -212,7 +223,7 @@ def main():
                        "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
-                       "parallelism": "batch-sharded x%d + RCCL min all-reduce" % world if use_dist else "single GPU",
+                       "parallelism": ("batch-sharded x%d + RCCL min all-reduce%s" % (world, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
@@ -220,6 +231,8 @@ def main():
         }
         print(json.dumps(out), flush=True)
 
+    if pipe is not None:
+        pipe.release()
     if frame is not None:
         frame.release()
     ctx.close()

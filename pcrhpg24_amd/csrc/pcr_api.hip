@@ -191,7 +191,8 @@ void pcr_destroy(pcr_ctx *c)
 int pcr_set_stream(pcr_ctx *c, void *hip_stream)
 {
     if (!c) return PCR_E_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // No synchronisation here: work already enqueued stays on the stream it was enqueued on, and ordering between
+    // the old and the new stream is the caller's (events), which is what lets a merge overlap the next render.
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return PCR_OK;
 }
@@ -454,7 +455,7 @@ int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
 {
     if (!c) return PCR_E_ARG;
     if (!c->own_fb) return set_err(c, PCR_E_ARG, "call pcr_set_image_size first");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // pointers are captured by value at enqueue time: switching them does not disturb work already enqueued
     c->fb = fb ? (uint64_t *)fb : c->own_fb;
     c->rg = rg ? (uint64_t *)rg : c->own_rg;
     c->ba = ba ? (uint64_t *)ba : c->own_ba;

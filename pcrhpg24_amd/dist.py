@@ -53,13 +53,17 @@ class DeviceFrame:
         from ._native import fb_elems
         n = fb_elems(width, height)
         self.ctx = ctx
+        self.device = device
         self.fb = torch.empty(n, dtype=torch.int64, device=device)
         self.rg = torch.zeros(n, dtype=torch.int64, device=device)
         self.ba = torch.zeros(n, dtype=torch.int64, device=device)
-        # all pcr work and the collectives are ordered on torch's current stream
-        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        ctx.use_external_buffers(self.fb.data_ptr(), self.rg.data_ptr(), self.ba.data_ptr())
-        ctx.clear()
+
+    def bind(self, stream=None):
+        """Make this frame the context's render target; pcr work goes to `stream` (default: torch's current)."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.ctx.set_stream(s.cuda_stream)
+        self.ctx.use_external_buffers(self.fb.data_ptr(), self.rg.data_ptr(), self.ba.data_ptr())
 
     def allreduce_min(self, group=None):
         import torch.distributed as dist
@@ -73,12 +77,13 @@ class DeviceFrame:
         dist.all_reduce(self.ba, op=dist.ReduceOp.SUM, group=group)
 
     def release(self):
+        self.ctx.synchronize()
         self.ctx.use_external_buffers(0, 0, 0)
         self.ctx.set_stream(0)
 
 
 def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None):
-    """One frame of the basic method on this rank's shard + the merge. Enqueue only."""
+    """One frame of the basic method on this rank's shard + the merge, all on one stream. Enqueue only."""
     ctx.clear()
     ctx.render_basic(params)
     if frame is not None:
@@ -95,3 +100,50 @@ def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: in
     if frame is not None:
         frame.allreduce_sum(group)
     ctx.resolve_hqs(params)
+
+
+class PipelinedBasicRenderer:
+    """Basic method over shards with the exchange step overlapped: frame k is merged (sign flip, RCCL min
+    all-reduce, flip back, resolve) on a communication stream while frame k+1 is already being decoded and
+    rasterized into the other of two framebuffers on the compute stream. HIP events order the two streams; results
+    are the same as the one-stream form, one frame later."""
+
+    def __init__(self, ctx, width: int, height: int, device, group=None):
+        import torch
+        self.ctx, self.device, self.group = ctx, device, group
+        self.frames = [DeviceFrame(ctx, width, height, device), DeviceFrame(ctx, width, height, device)]
+        self.compute = torch.cuda.Stream(device)
+        self.comm = torch.cuda.Stream(device)
+        self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
+        self.merged = [torch.cuda.Event(), torch.cuda.Event()]
+        self.k = 0
+        for e in self.merged:
+            e.record(self.comm)
+
+    def step(self, params):
+        import torch
+        i = self.k & 1
+        f = self.frames[i]
+        self.compute.wait_event(self.merged[i])        # this framebuffer's previous merge + resolve are done
+        f.bind(self.compute)
+        self.ctx.clear()
+        self.ctx.render_basic(params)
+        self.rendered[i].record(self.compute)
+        self.comm.wait_event(self.rendered[i])
+        with torch.cuda.stream(self.comm):             # RCCL orders itself against torch's current stream
+            f.bind(self.comm)
+            f.allreduce_min(self.group)
+            self.ctx.resolve_basic(params)
+            self.merged[i].record(self.comm)
+        self.k += 1
+
+    def last_frame(self) -> DeviceFrame:
+        return self.frames[(self.k - 1) & 1]
+
+    def finish(self):
+        self.compute.synchronize()
+        self.comm.synchronize()
+
+    def release(self):
+        self.finish()
+        self.frames[0].release()
