@@ -1,0 +1,170 @@
+"""GPU parity on the corners of the path: wide table values, escape-pool overflow, tiny and huge images, LOD 0,
+window rectangles clipped by the screen, reload / resize cycles, two contexts on one device."""
+import numpy as np
+import pytest
+
+import pcrhpg24_amd as P
+from tests import oracle, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def check_all(ctx, of, p):
+    ctx.clear(); ctx.render_basic(p); ctx.resolve_basic(p)
+    ofb, ost = of.render_basic(p)
+    assert ctx.stats() == ost
+    fb = ctx.read_framebuffer(full=True)
+    bad = np.nonzero(fb != ofb)[0]
+    assert bad.size == 0, f"basic: {bad.size} words differ, first {bad[:4]}"
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(p, ofb))
+    ctx.clear(); ctx.render_hqs_depth(p)
+    hfb, hst = of.render_hqs_depth(p)
+    assert ctx.stats() == hst and np.array_equal(ctx.read_framebuffer(full=True), hfb)
+    ctx.render_hqs_color(p); ctx.resolve_hqs(p)
+    org, oba, _ = of.render_hqs_color(p, hfb)
+    rg, ba = ctx.read_accum(full=True)
+    assert np.array_equal(rg, org) and np.array_equal(ba, oba)
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_hqs(p, hfb, org, oba))
+    return ost
+
+
+def load(ctx, image):
+    f = P.HuffmanFile(image)
+    if ctx.batches_loaded:
+        ctx.stream_unload()
+    ctx.stream_begin(f.header())
+    for b in range(f.numBatches):
+        ctx.upload_batch(b, f.blob(b))
+    return f
+
+
+@pytest.fixture()
+def ctx():
+    c = P.Context(0)
+    yield c
+    c.close()
+
+
+def las_for(lo, hi, scale=0.001):
+    las = P.LasInfo()
+    for k in range(3):
+        las.scale[k] = scale; las.offset[k] = 0.0; las.min[k] = lo[k] * scale; las.max[k] = hi[k] * scale
+    return las
+
+
+def test_wide_table_values(ctx):
+    """Frequent symbols that do not fit the 26-bit packed LDS entry (+-2^30 deltas with short codes)."""
+    rng = np.random.default_rng(21)
+    n = 65536 * 2
+    hop = np.where(np.arange(n) % 2 == 0, 0, 1 << 30).astype(np.int64)
+    x = (hop + rng.integers(0, 3, n)).astype(np.int32)
+    y = rng.integers(0, 2000, n).astype(np.int32)
+    z = rng.integers(0, 50, n).astype(np.int32)
+    c = rng.integers(0, 1 << 24, n).astype(np.uint32)
+    image, st = P.encode_points(x, y, z, c, las_for((0, 0, 0), (1 << 30, 2000, 50)), morton_sort=False, nthreads=2)
+    of = oracle.OracleFile(image.view())
+    tv = np.ctypeslib.as_array(__import__("ctypes").cast(of.s.dt_values, __import__("ctypes").POINTER(__import__("ctypes").c_int32)), (4096,))
+    tl = np.ctypeslib.as_array(__import__("ctypes").cast(of.s.dt_cwlen, __import__("ctypes").POINTER(__import__("ctypes").c_int32)), (4096,))
+    assert (np.abs(tv[tl > 0].astype(np.int64)) >= 1 << 25).any(), "the stream must contain in-table values wider than 26 bits"
+    ctx.set_image_size(320, 200)
+    load(ctx, image)
+    p = scenes.with_flags(P.camera_orbit(0.2, -0.8, 3.0e6, (5.0e5, 1.0, 0.0), 320, 200), lod_percent=100, cull=0)
+    st = check_all(ctx, of, p)
+    assert st["points_iterated"] == n
+
+
+def test_escape_pool_overflow_and_lod_zero(ctx):
+    """Escape-heavy batches read their escapes from global memory; lod_percent 0 lets far batches render 0 points."""
+    x, y, z, c, las = scenes.random_points(131072, seed=3)
+    image, st = P.encode_points(x, y, z, c, las, morton_sort=True, nthreads=2)
+    assert st["escaped_symbols"] > 6144 * st["num_batches"]
+    of = oracle.OracleFile(image.view())
+    ctx.set_image_size(256, 144)
+    load(ctx, image)
+    for rad, lod in ((2000.0, 100), (400000.0, 0), (9000.0, 0)):
+        p = scenes.with_flags(P.camera_orbit(0.5, -0.6, rad, (100.0, 100.0, 100.0), 256, 144), lod_percent=lod)
+        check_all(ctx, of, p)
+
+
+@pytest.mark.parametrize("size", [(64, 36), (33, 97), (4096, 4096)])
+def test_image_sizes_and_clipped_windows(ctx, size):
+    w, h = size
+    image, _ = scenes.synth_stream(600_000)
+    of = oracle.OracleFile(image.view())
+    ctx.set_image_size(w, h)
+    load(ctx, image)
+    cams = [P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h),
+            P.camera_orbit(-1.68, -0.39, 70.0, (300.0, 20.0, 45.0), w, h),        # batches straddle the screen border
+            P.camera_orbit(0.3, -1.2, 900.0, (0.0, 0.0, 40.0), w, h)]              # tile corner at the screen centre
+    for p in cams:
+        for lod, cull in ((100, 1), (10, 1)):
+            check_all(ctx, of, scenes.with_flags(p, lod_percent=lod, cull=cull))
+
+
+def test_reload_resize_and_two_contexts(ctx):
+    a, _ = scenes.synth_stream(200_000)
+    b, _ = scenes.synth_stream(600_000)
+    oa, ob = oracle.OracleFile(a.view()), oracle.OracleFile(b.view())
+    other = P.Context(0)
+    try:
+        for image, of, (w, h) in ((a, oa, (200, 120)), (b, ob, (400, 240)), (a, oa, (128, 128))):
+            ctx.set_image_size(w, h)
+            other.set_image_size(w, h)
+            load(ctx, image)
+            load(other, image)
+            p = scenes.with_flags(P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h), lod_percent=50)
+            check_all(ctx, of, p)
+            # interleaved use of a second context on the same device
+            other.clear(); other.render_basic(p)
+            ctx.clear(); ctx.render_basic(p)
+            assert np.array_equal(other.read_framebuffer(full=True), ctx.read_framebuffer(full=True))
+    finally:
+        other.close()
+
+
+def test_sharded_contexts_merge_to_the_single_context_result(ctx):
+    """Two contexts each hold one contiguous batch range (+ the follower's head words); pcr_merge_min / pcr_merge_sum
+    of their framebuffers equal the unsharded render — the multi-GPU exchange step, on one device."""
+    image, _ = scenes.synth_stream(600_000)
+    f = P.HuffmanFile(image)
+    of = oracle.OracleFile(image.view())
+    w, h = 320, 180
+    shard = P.Context(0)
+    try:
+        ctxs = [ctx, shard]
+        half = f.numBatches // 2
+        ranges = [(0, half), (half, f.numBatches - half)]
+        for c, (first, count) in zip(ctxs, ranges):
+            c.set_image_size(w, h)
+            c.stream_begin(f.header(first, count), first)
+            for i in range(count):
+                c.upload_batch(i, f.blob(first + i))
+            if first + count < f.numBatches:
+                c.upload_tail(*f.head_words(first + count))
+        p = scenes.with_flags(P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h), lod_percent=100)
+        for c in ctxs:
+            c.clear(); c.render_basic(p)
+        shard.synchronize()
+        ctx.merge_min(shard.device_framebuffer())
+        ofb, _ = of.render_basic(p)
+        assert np.array_equal(ctx.read_framebuffer(full=True), ofb)
+        # HQS: min-merge depth both ways, colour pass against the global depth, sum-merge
+        for c in ctxs:
+            c.clear(); c.render_hqs_depth(p)
+        shard.synchronize(); ctx.synchronize()
+        ctx.merge_min(shard.device_framebuffer()); ctx.synchronize()
+        shard.merge_min(ctx.device_framebuffer())
+        for c in ctxs:
+            c.render_hqs_color(p)
+        shard.synchronize()
+        lib = ctx.lib
+        ctx.merge_sum(int(lib.pcr_device_rg(shard.h)), int(lib.pcr_device_ba(shard.h)))
+        hfb, _ = of.render_hqs_depth(p)
+        org, oba, _ = of.render_hqs_color(p, hfb)
+        rg, ba = ctx.read_accum(full=True)
+        assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
+        assert np.array_equal(rg, org) and np.array_equal(ba, oba)
+        ctx.flip_sign(); ctx.flip_sign()
+        assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
+    finally:
+        shard.close()
