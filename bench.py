@@ -100,8 +100,8 @@ def main():
     ctx.set_image_size(args.width, args.height)
     t0 = time.time()
     ctx.stream_begin(hf.header(), 0)
-    for b in range(hf.numBatches):
-        ctx.upload_batch(b, hf.blob(b))
+    for b0 in range(0, hf.numBatches, 100):          # loader tasks of <= 100 records, as HuffmanLasData::process
+        ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
     if world > 1:
         # shard boundary: the words that follow this shard in the global stream
         enc_h, sep_h = hf.head_words(0)

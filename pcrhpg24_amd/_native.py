@@ -65,7 +65,7 @@ def fb_elems(w: int, h: int) -> int:
 
 HIP_SYMBOLS = [
     "pcr_create", "pcr_destroy", "pcr_last_error", "pcr_set_stream", "pcr_synchronize",
-    "pcr_stream_begin", "pcr_upload_batch", "pcr_upload_tail", "pcr_stream_unload", "pcr_batches_loaded",
+    "pcr_stream_begin", "pcr_upload_batch", "pcr_upload_batches", "pcr_upload_tail", "pcr_stream_unload", "pcr_batches_loaded",
     "pcr_points_loaded", "pcr_set_image_size", "pcr_clear", "pcr_render_basic", "pcr_render_hqs_depth",
     "pcr_render_hqs_color", "pcr_resolve_basic", "pcr_resolve_hqs", "pcr_get_stats", "pcr_read_framebuffer",
     "pcr_read_accum", "pcr_read_rgba", "pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba",
@@ -107,6 +107,7 @@ def hip_lib() -> C.CDLL:
         lib.pcr_synchronize.argtypes = [C.c_void_p]
         lib.pcr_stream_begin.argtypes = [C.c_void_p, C.POINTER(FileHeader), c_i64]
         lib.pcr_upload_batch.argtypes = [C.c_void_p, c_i64, C.c_void_p, C.c_size_t]
+        lib.pcr_upload_batches.argtypes = [C.c_void_p, c_i64, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.pcr_upload_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         lib.pcr_stream_unload.argtypes = [C.c_void_p]
         lib.pcr_set_image_size.argtypes = [C.c_void_p, C.c_int, C.c_int]

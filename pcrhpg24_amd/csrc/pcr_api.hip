@@ -41,7 +41,12 @@ struct pcr_ctx {
     uint32_t *d_lod = nullptr;
     uint2 *d_win = nullptr;
     pcr_render_stats *d_stats = nullptr;
-    std::vector<int8_t> lens_scratch;
+    // pinned staging arenas of the loader (double-buffered)
+    uint8_t *arena[2] = {nullptr, nullptr};
+    size_t arena_size[2] = {0, 0};
+    hipEvent_t arena_done[2] = {nullptr, nullptr};
+    bool arena_busy[2] = {false, false};
+    int arena_next = 0;
 
     // method (framebuffers)
     int width = 0, height = 0;
@@ -164,6 +169,8 @@ int pcr_create(int device, pcr_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
+        hipEventCreateWithFlags(&c->arena_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->arena_done[1], hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->d_stats, sizeof(pcr_render_stats)) != hipSuccess) {
         pcr_destroy(c);
         return set_err(nullptr, PCR_E_HIP, "could not create stream/events");
@@ -182,6 +189,10 @@ void pcr_destroy(pcr_ctx *c)
     free_stream_buffers(c);
     free_frame_buffers(c);
     dfree(c->d_stats);
+    for (int i = 0; i < 2; ++i) {
+        if (c->arena[i]) (void)hipHostFree(c->arena[i]);
+        if (c->arena_done[i]) (void)hipEventDestroy(c->arena_done[i]);
+    }
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -238,86 +249,144 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
 
 int pcr_upload_batch(pcr_ctx *c, int64_t batch_index, const void *blob, size_t n)
 {
+    return pcr_upload_batches(c, batch_index, 1, &blob, &n);
+}
+
+// One loader task (the reference hands over <= 100 records at a time, HuffmanLasLoader.cpp:106): every record is
+// validated, the nine per-batch arrays of the whole task are packed contiguously into one of two pinned staging
+// arenas, and nine large asynchronous copies move them; the arenas alternate, so packing task k+1 on the host
+// overlaps the copies of task k. The reference issues nine synchronous cuMemcpyHtoD per record instead
+// (HuffmanLasLoader.cpp:229-289).
+int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const void *const *blobs, const size_t *sizes)
+{
     if (!c) return PCR_E_ARG;
     if (!c->stream_open) return set_err(c, PCR_E_ARG, "pcr_stream_begin has not been called");
-    if (!blob) return set_err(c, PCR_E_ARG, "blob is NULL");
-    if (batch_index != c->batches_loaded)
-        return set_err(c, PCR_E_ARG, "batches must be uploaded in order: expected %lld, got %lld", (long long)c->batches_loaded, (long long)batch_index);
-    if (batch_index >= c->hdr.num_batches) return set_err(c, PCR_E_ARG, "batch index %lld beyond header", (long long)batch_index);
-    const uint8_t *r = (const uint8_t *)blob;
+    if (count <= 0 || !blobs || !sizes) return set_err(c, PCR_E_ARG, "no batch records given");
+    if (first_index != c->batches_loaded)
+        return set_err(c, PCR_E_ARG, "batches must be uploaded in order: expected %lld, got %lld", (long long)c->batches_loaded, (long long)first_index);
+    if (first_index + count > c->hdr.num_batches) return set_err(c, PCR_E_ARG, "batch index %lld beyond header", (long long)(first_index + count - 1));
+
     const size_t fixed = PCR_BATCH_FIXED_HEADER + 4u * (3072 + 1024 + 4096 + 4096 + 32);
-    if (n < fixed) return set_err(c, PCR_E_FORMAT, "batch %lld: record of %zu bytes is too short", (long long)batch_index, n);
-    // include/BatchDumpData.h:60-107
-    int32_t hdr[5]; std::memcpy(hdr, r, 20);
-    double sc[3], of[3]; float bmin[3], bmax[3], lmin[3], lmax[3]; int32_t dt_size, num_clusters;
-    std::memcpy(sc, r + 20, 24); std::memcpy(of, r + 44, 24);
-    std::memcpy(bmin, r + 68, 12); std::memcpy(bmax, r + 80, 12);
-    std::memcpy(lmin, r + 92, 12); std::memcpy(lmax, r + 104, 12);
-    std::memcpy(&dt_size, r + 116, 4); std::memcpy(&num_clusters, r + 120, 4);
-    if (hdr[1] != PCR_POINTS_PER_BATCH || hdr[2] != PCR_WORKGROUP_SIZE || hdr[3] != PCR_POINTS_PER_THREAD ||
-        hdr[4] != PCR_CLUSTERS_PER_THREAD || dt_size != PCR_HUFFMAN_TABLE_SIZE || num_clusters != PCR_CLUSTERS_PER_BATCH)
-        return set_err(c, PCR_E_FORMAT, "batch %lld: unsupported geometry (points %d threads %d ppt %d cpt %d table %d clusters %d)",
-                       (long long)batch_index, hdr[1], hdr[2], hdr[3], hdr[4], dt_size, num_clusters);
-    const uint8_t *p_start = r + PCR_BATCH_FIXED_HEADER;
-    const uint8_t *p_sepsz = p_start + 3072 * 4;
-    const uint8_t *p_tv = p_sepsz + 1024 * 4;
-    const uint8_t *p_tl = p_tv + 4096 * 4;
-    const uint8_t *p_cl = p_tl + 4096 * 4;
-    const uint8_t *p_enc = p_cl + 32 * 4;
-    int32_t ne, ns;
-    std::memcpy(&ne, p_cl + 31 * 4, 4);
-    std::memcpy(&ns, p_sepsz + 1023 * 4, 4);
-    if (ne < 64 || ns < 0 || n != fixed + 4u * ((size_t)ne + (size_t)ns) + PCR_COLOR_BYTES_PER_BATCH)   // BatchDumpData.h:148
-        return set_err(c, PCR_E_FORMAT, "batch %lld: record size %zu does not match its stream lengths", (long long)batch_index, n);
-    if (c->enc_ptr + ne > c->enc_words - PCR_ENCODED_PAD_WORDS || c->sep_ptr + ns > c->sep_words - PCR_SEPARATE_PAD_WORDS)
-        return set_err(c, PCR_E_FORMAT, "batch %lld: streams exceed the header's byte counts", (long long)batch_index);
-    // table lengths: validate and narrow to int8 (render.cu:393 narrows to char in-kernel)
-    c->lens_scratch.resize(4096);
-    for (int i = 0; i < 4096; ++i) {
-        int32_t l; std::memcpy(&l, p_tl + 4 * i, 4);
-        if (l == 0 || l > PCR_MAX_CW_LEN || l < -PCR_MAX_CW_LEN)
-            return set_err(c, PCR_E_FORMAT, "batch %lld: decoder table entry %d has code length %d", (long long)batch_index, i, l);
-        c->lens_scratch[(size_t)i] = (int8_t)l;
-    }
-    // monotone prefixes keep every in-range read inside the batch's own data
-    {
-        int32_t prev = 0;
-        for (int i = 0; i < 32; ++i) { int32_t v; std::memcpy(&v, p_cl + 4 * i, 4); if (v < prev) return set_err(c, PCR_E_FORMAT, "batch %lld: cluster sizes not monotone", (long long)batch_index); prev = v; }
+    struct View { const uint8_t *start, *sepsz, *tv, *tl, *cl, *enc, *sep, *col; int32_t ne, ns; };
+    std::vector<View> views((size_t)count);
+    int64_t sum_ne = 0, sum_ns = 0;
+    // ---- pass 1: validate (nothing is modified if any record is bad) --------------------------------------------
+    for (int64_t k = 0; k < count; ++k) {
+        const int64_t bi = first_index + k;
+        const uint8_t *r = (const uint8_t *)blobs[k];
+        const size_t n = sizes[k];
+        if (!r) return set_err(c, PCR_E_ARG, "blob is NULL");
+        if (n < fixed) return set_err(c, PCR_E_FORMAT, "batch %lld: record of %zu bytes is too short", (long long)bi, n);
+        int32_t hdr[5]; std::memcpy(hdr, r, 20);                      // include/BatchDumpData.h:60-107
+        int32_t dt_size, num_clusters;
+        std::memcpy(&dt_size, r + 116, 4); std::memcpy(&num_clusters, r + 120, 4);
+        if (hdr[1] != PCR_POINTS_PER_BATCH || hdr[2] != PCR_WORKGROUP_SIZE || hdr[3] != PCR_POINTS_PER_THREAD ||
+            hdr[4] != PCR_CLUSTERS_PER_THREAD || dt_size != PCR_HUFFMAN_TABLE_SIZE || num_clusters != PCR_CLUSTERS_PER_BATCH)
+            return set_err(c, PCR_E_FORMAT, "batch %lld: unsupported geometry (points %d threads %d ppt %d cpt %d table %d clusters %d)",
+                           (long long)bi, hdr[1], hdr[2], hdr[3], hdr[4], dt_size, num_clusters);
+        View &v = views[(size_t)k];
+        v.start = r + PCR_BATCH_FIXED_HEADER;
+        v.sepsz = v.start + 3072 * 4;
+        v.tv = v.sepsz + 1024 * 4;
+        v.tl = v.tv + 4096 * 4;
+        v.cl = v.tl + 4096 * 4;
+        v.enc = v.cl + 32 * 4;
+        std::memcpy(&v.ne, v.cl + 31 * 4, 4);
+        std::memcpy(&v.ns, v.sepsz + 1023 * 4, 4);
+        if (v.ne < 64 || v.ns < 0 || n != fixed + 4u * ((size_t)v.ne + (size_t)v.ns) + PCR_COLOR_BYTES_PER_BATCH)   // BatchDumpData.h:148
+            return set_err(c, PCR_E_FORMAT, "batch %lld: record size %zu does not match its stream lengths", (long long)bi, n);
+        v.sep = v.enc + (size_t)v.ne * 4;
+        v.col = v.sep + (size_t)v.ns * 4;
+        sum_ne += v.ne; sum_ns += v.ns;
+        if (c->enc_ptr + sum_ne > c->enc_words - PCR_ENCODED_PAD_WORDS || c->sep_ptr + sum_ns > c->sep_words - PCR_SEPARATE_PAD_WORDS)
+            return set_err(c, PCR_E_FORMAT, "batch %lld: streams exceed the header's byte counts", (long long)bi);
+        for (int i = 0; i < 4096; ++i) {                              // code lengths (narrowed to int8 below)
+            int32_t l; std::memcpy(&l, v.tl + 4 * i, 4);
+            if (l == 0 || l > PCR_MAX_CW_LEN || l < -PCR_MAX_CW_LEN)
+                return set_err(c, PCR_E_FORMAT, "batch %lld: decoder table entry %d has code length %d", (long long)bi, i, l);
+        }
+        int32_t prev = 0;                                             // monotone prefixes keep in-range reads inside the batch
+        for (int i = 0; i < 32; ++i) { int32_t x; std::memcpy(&x, v.cl + 4 * i, 4); if (x < prev) return set_err(c, PCR_E_FORMAT, "batch %lld: cluster sizes not monotone", (long long)bi); prev = x; }
         prev = 0;
-        for (int i = 0; i < 1024; ++i) { int32_t v; std::memcpy(&v, p_sepsz + 4 * i, 4); if (v < prev) return set_err(c, PCR_E_FORMAT, "batch %lld: separate sizes not monotone", (long long)batch_index); prev = v; }
+        for (int i = 0; i < 1024; ++i) { int32_t x; std::memcpy(&x, v.sepsz + 4 * i, 4); if (x < prev) return set_err(c, PCR_E_FORMAT, "batch %lld: separate sizes not monotone", (long long)bi); prev = x; }
     }
-    const uint8_t *p_sep = p_enc + (size_t)ne * 4;
-    const uint8_t *p_col = p_sep + (size_t)ns * 4;
 
-    pcr_gpu_batch g;                                  // HuffmanLasLoader.cpp:188-211
-    g.min_x = bmin[0]; g.min_y = bmin[1]; g.min_z = bmin[2];
-    g.max_x = bmax[0]; g.max_y = bmax[1]; g.max_z = bmax[2];
-    g.scale_x = sc[0]; g.scale_y = sc[1]; g.scale_z = sc[2];
-    g.offset_x = of[0]; g.offset_y = of[1]; g.offset_z = of[2];
-    g.las_min_x = lmin[0]; g.las_min_y = lmin[1]; g.las_min_z = lmin[2];
-    g.las_max_x = lmax[0]; g.las_max_y = lmax[1]; g.las_max_z = lmax[2];
-    g.encoding_batch_offset = c->enc_ptr;
-    g.separate_batch_offset = c->sep_ptr;
-    g.decoder_table_offset = batch_index * 4096;
-    g.cluster_sizes_offset = batch_index * 32;
-    g.max_cw_len = PCR_MAX_CW_LEN;
-
+    // ---- pass 2: pack into the free pinned arena ------------------------------------------------------------------
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t b = (size_t)batch_index;
+    const size_t nb = (size_t)count;
+    const size_t o_batches = 0;
+    const size_t o_start = o_batches + nb * sizeof(pcr_gpu_batch);
+    const size_t o_sepsz = o_start + nb * 3072 * 4;
+    const size_t o_tv = o_sepsz + nb * 1024 * 4;
+    const size_t o_tl = o_tv + nb * 4096 * 4;
+    const size_t o_cl = o_tl + nb * 4096;
+    const size_t o_col = o_cl + nb * 32 * 4;
+    const size_t o_enc = o_col + nb * PCR_COLOR_BYTES_PER_BATCH;
+    const size_t o_sep = o_enc + (size_t)sum_ne * 4;
+    const size_t total = o_sep + (size_t)sum_ns * 4;
+    const int slot = c->arena_next;
+    c->arena_next ^= 1;
+    if (c->arena_busy[slot]) { HIP_TRY(c, hipEventSynchronize(c->arena_done[slot])); c->arena_busy[slot] = false; }
+    if (c->arena_size[slot] < total) {
+        if (c->arena[slot]) { (void)hipHostFree(c->arena[slot]); c->arena[slot] = nullptr; c->arena_size[slot] = 0; }
+        const size_t want = total + total / 4 + 4096;
+        HIP_TRY(c, hipHostMalloc((void **)&c->arena[slot], want, hipHostMallocDefault));
+        c->arena_size[slot] = want;
+    }
+    uint8_t *A = c->arena[slot];
+    int64_t enc_ptr = c->enc_ptr, sep_ptr = c->sep_ptr;
+    size_t eo = 0, so = 0;
+    for (int64_t k = 0; k < count; ++k) {
+        const View &v = views[(size_t)k];
+        const uint8_t *r = (const uint8_t *)blobs[k];
+        double sc[3], of[3]; float bmin[3], bmax[3], lmin[3], lmax[3];
+        std::memcpy(sc, r + 20, 24); std::memcpy(of, r + 44, 24);
+        std::memcpy(bmin, r + 68, 12); std::memcpy(bmax, r + 80, 12);
+        std::memcpy(lmin, r + 92, 12); std::memcpy(lmax, r + 104, 12);
+        pcr_gpu_batch g;                                  // HuffmanLasLoader.cpp:188-211
+        g.min_x = bmin[0]; g.min_y = bmin[1]; g.min_z = bmin[2];
+        g.max_x = bmax[0]; g.max_y = bmax[1]; g.max_z = bmax[2];
+        g.scale_x = sc[0]; g.scale_y = sc[1]; g.scale_z = sc[2];
+        g.offset_x = of[0]; g.offset_y = of[1]; g.offset_z = of[2];
+        g.las_min_x = lmin[0]; g.las_min_y = lmin[1]; g.las_min_z = lmin[2];
+        g.las_max_x = lmax[0]; g.las_max_y = lmax[1]; g.las_max_z = lmax[2];
+        g.encoding_batch_offset = enc_ptr;
+        g.separate_batch_offset = sep_ptr;
+        g.decoder_table_offset = (first_index + k) * 4096;
+        g.cluster_sizes_offset = (first_index + k) * 32;
+        g.max_cw_len = PCR_MAX_CW_LEN;
+        const size_t kk = (size_t)k;
+        std::memcpy(A + o_batches + kk * sizeof g, &g, sizeof g);
+        std::memcpy(A + o_start + kk * 3072 * 4, v.start, 3072 * 4);
+        std::memcpy(A + o_sepsz + kk * 1024 * 4, v.sepsz, 1024 * 4);
+        std::memcpy(A + o_tv + kk * 4096 * 4, v.tv, 4096 * 4);
+        int8_t *tl8 = (int8_t *)(A + o_tl + kk * 4096);
+        for (int i = 0; i < 4096; ++i) { int32_t l; std::memcpy(&l, v.tl + 4 * i, 4); tl8[i] = (int8_t)l; }   // render.cu:393
+        std::memcpy(A + o_cl + kk * 32 * 4, v.cl, 32 * 4);
+        std::memcpy(A + o_col + kk * PCR_COLOR_BYTES_PER_BATCH, v.col, PCR_COLOR_BYTES_PER_BATCH);
+        std::memcpy(A + o_enc + eo, v.enc, (size_t)v.ne * 4); eo += (size_t)v.ne * 4;
+        std::memcpy(A + o_sep + so, v.sep, (size_t)v.ns * 4); so += (size_t)v.ns * 4;
+        enc_ptr += v.ne; sep_ptr += v.ns;
+    }
+
+    // ---- nine copies for the whole task ---------------------------------------------------------------------------
+    const size_t b0 = (size_t)first_index;
     hipStream_t st = c->stream;
-    // pageable-source async copies are staged by the runtime before returning, so `blob` may be released after the call
-    HIP_TRY(c, hipMemcpyAsync(c->d_batches + b, &g, sizeof g, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_start + b * 3072, p_start, 3072 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_sep_sizes + b * 1024, p_sepsz, 1024 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_table_values + b * 4096, p_tv, 4096 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_table_lens + b * 4096, c->lens_scratch.data(), 4096, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_cluster_sizes + b * 32, p_cl, 32 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_encoded + c->enc_ptr, p_enc, (size_t)ne * 4, hipMemcpyHostToDevice, st));
-    if (ns) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, p_sep, (size_t)ns * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_colors + b * PCR_COLOR_BYTES_PER_BATCH, p_col, PCR_COLOR_BYTES_PER_BATCH, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipStreamSynchronize(st));             // lens_scratch and `blob` are reusable on return
-    c->enc_ptr += ne; c->sep_ptr += ns;
-    c->batches_loaded += 1; c->points_loaded += hdr[1];   // HuffmanLasLoader.cpp:294-295
+    HIP_TRY(c, hipMemcpyAsync(c->d_batches + b0, A + o_batches, nb * sizeof(pcr_gpu_batch), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_start + b0 * 3072, A + o_start, nb * 3072 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_sep_sizes + b0 * 1024, A + o_sepsz, nb * 1024 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_table_values + b0 * 4096, A + o_tv, nb * 4096 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_table_lens + b0 * 4096, A + o_tl, nb * 4096, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cluster_sizes + b0 * 32, A + o_cl, nb * 32 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_colors + b0 * PCR_COLOR_BYTES_PER_BATCH, A + o_col, nb * PCR_COLOR_BYTES_PER_BATCH, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_encoded + c->enc_ptr, A + o_enc, (size_t)sum_ne * 4, hipMemcpyHostToDevice, st));
+    if (sum_ns) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, A + o_sep, (size_t)sum_ns * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipEventRecord(c->arena_done[slot], st));
+    c->arena_busy[slot] = true;
+    // the caller's records were copied into the arena: they may be released on return; the device copies complete in
+    // stream order before any later render call
+    c->enc_ptr = enc_ptr; c->sep_ptr = sep_ptr;
+    c->batches_loaded += count; c->points_loaded += count * PCR_POINTS_PER_BATCH;   // HuffmanLasLoader.cpp:294-295
     return PCR_OK;
 }
 

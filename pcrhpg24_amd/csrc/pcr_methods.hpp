@@ -186,10 +186,11 @@ struct HuffmanLasData : Resource {
     {
         std::lock_guard<std::mutex> lock(mtx_tasks);
         if (!task) return;
-        for (size_t i = 0; i < task->batchIndices.size(); ++i) {
-            renderer->check(pcr_upload_batch(renderer->ctx, task->batchIndices[i], task->buffers[i].data(), task->buffers[i].size()),
-                            "pcr_upload_batch");
-        }
+        std::vector<const void *> blobs;
+        std::vector<size_t> sizes;
+        for (size_t i = 0; i < task->batchIndices.size(); ++i) { blobs.push_back(task->buffers[i].data()); sizes.push_back(task->buffers[i].size()); }
+        renderer->check(pcr_upload_batches(renderer->ctx, task->batchIndices.front(), (int64_t)blobs.size(), blobs.data(), sizes.data()),
+                        "pcr_upload_batches");
         numBatchesLoaded = pcr_batches_loaded(renderer->ctx);
         numPointsLoaded = pcr_points_loaded(renderer->ctx);
         task = nullptr;

@@ -224,6 +224,14 @@ class Context:
         arr = np.frombuffer(mv, np.uint8)
         self._chk(self.lib.pcr_upload_batch(self.h, index, arr.ctypes.data, len(mv)), "pcr_upload_batch")
 
+    def upload_batches(self, first: int, blobs) -> None:
+        """One loader task: `blobs` are the records of batches first, first+1, ... (buffer-protocol objects)."""
+        arrs = [np.frombuffer(memoryview(b).cast("B"), np.uint8) for b in blobs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * n)(*[a.size for a in arrs])
+        self._chk(self.lib.pcr_upload_batches(self.h, first, n, ptrs, sizes), "pcr_upload_batches")
+
     def upload_tail(self, enc: np.ndarray, sep: np.ndarray) -> None:
         enc = np.ascontiguousarray(enc, np.uint32); sep = np.ascontiguousarray(sep, np.int32)
         self._chk(self.lib.pcr_upload_tail(self.h, enc.ctypes.data, len(enc), sep.ctypes.data, len(sep)), "pcr_upload_tail")
@@ -438,8 +446,7 @@ class HuffmanLasData(Resource):
         if self.state not in (Resource.LOADING,):
             return
         end = min(self.numBatches, self._next + self.BATCHES_PER_TASK)
-        for i in range(self._next, end):
-            renderer.ctx.upload_batch(i, self.file.blob(self.first_batch + i))
+        renderer.ctx.upload_batches(self._next, [self.file.blob(self.first_batch + i) for i in range(self._next, end)])
         self._next = end
         self.numBatchesLoaded = renderer.ctx.batches_loaded
         self.numPointsLoaded = renderer.ctx.points_loaded
