@@ -32,7 +32,8 @@ constexpr int ESC_POOL_WORDS = 6144;             // escape words of the whole ba
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
 constexpr int WIN_PIXELS     = 2560;             // u64 framebuffer window of the batch's rectangle -> 20 KiB
 constexpr int WIN_PIXELS_HQS = 1024;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 20 KiB
-constexpr uint32_t TE_LEN = 15u, TE_ESCAPE = 16u, TE_WIDE = 32u;   // packed table entry fields (value in bits 31:6)
+constexpr uint32_t TE_LEN = 0xFFu, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u;   // packed table entry: len in byte 0, flags, value in bits 31:10
+constexpr int TE_VALUE_SHIFT = 10;
 
 // Device-side view of the loaded stream (own layout; the reference keeps nine flat CuBuffers,
 // HuffmanLasLoader.h:39-47). Tables are stored as int32 values + int8 lengths (the reference narrows the
@@ -177,8 +178,8 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
 // decode + rasterize: one workgroup per batch, 16 wave64 = 32 stream clusters
 //
 // Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
-//   s_table  16 KiB  decoder table packed to one dword per key: value<<6 | wide<<5 | escape<<4 | len
-//                    (a table value that does not fit 26 bits is flagged `wide` and re-read from global memory)
+//   s_table  16 KiB  decoder table packed to one dword per key: value<<10 | wide<<9 | escape<<8 | len
+//                    (a table value that does not fit 22 bits is flagged `wide` and re-read from global memory)
 //   s_ring   16 KiB  per cluster a 128-word ring of its word stream, filled 64 words at a time by coalesced
 //                    8-byte-per-lane loads issued one chunk ahead and staged in registers, so the per-symbol
 //                    refill is an LDS read instead of a dependent global load
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             const int len = (int)(int8_t)lbyte;                             // render.cu:393 narrows to char
             const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE : 0u);
             if (len <= 0) return f;                                         // escapes never use the table value
-            return ((int32_t)((uint32_t)value << 6) >> 6) == value ? (((uint32_t)value << 6) | f) : (f | TE_WIDE);
+            return ((int32_t)((uint32_t)value << TE_VALUE_SHIFT) >> TE_VALUE_SHIFT) == value ? (((uint32_t)value << TE_VALUE_SHIFT) | f) : (f | TE_WIDE);
         };
         uint4 e;
         e.x = pack(v.x, l4 & 0xFF); e.y = pack(v.y, (l4 >> 8) & 0xFF);
@@ -323,14 +324,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // ---- word stream of my cluster: words 0..63 straight to registers, chunks 1,2 to the ring, chunk 3 staged
     const uint32_t cbase = cluster ? (uint32_t)a.s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;   // :407-410
     uint32_t *ring = s_ring + cluster * RING_WORDS;
-    uint32_t cur = enc_load(cbase + lane32);                // :416
-    uint32_t nxt = enc_load(cbase + 32 + lane32);           // :417
+    uint64_t bits = ((uint64_t)enc_load(cbase + lane32) << 32) | enc_load(cbase + 32 + lane32);   // {CurHuffman, NextHuffman} :416-417
     reinterpret_cast<uint2 *>(ring + CHUNK_WORDS)[lane32] = enc_load2(cbase + CHUNK_WORDS + lane32 * 2);
     reinterpret_cast<uint2 *>(ring)[lane32] = enc_load2(cbase + 2 * CHUNK_WORDS + lane32 * 2);
     uint2 stage = enc_load2(cbase + 3 * CHUNK_WORDS + lane32 * 2);
     uint32_t ep = 64;                                       // already_read (:418): next stream word of the cluster
     uint32_t next_cross = 2 * CHUNK_WORDS;                  // ep value at which the ring's older chunk is dead
-    int cur_bits = 32;                                      // :419
+    uint32_t sft = 32 + 18;                                 // cur_bits (:419) + 18, see the decode step
 
     const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + tid) * 3;   // :421-424
     int32_t px = sv[0], py = sv[1], pz = sv[2];
@@ -427,10 +427,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {                                   // :430
-                const uint64_t w = ((uint64_t)cur << 32) | nxt;
-                const uint32_t key = (uint32_t)(w >> (20 + cur_bits)) & 0xFFFu;
-                const uint32_t e = s_table[key];                            // :435-436
-                int32_t val = (int32_t)e >> 6;
+                // bits is {cur, nxt}; sft = cur_bits + 18, so (bits >> sft) & 0x3FFC is 4 x the 12-bit window of
+                // :431-433 (== ((L|R) & mask) >> 20), i.e. the byte offset of its table entry
+                const uint32_t toff = (uint32_t)(bits >> sft) & 0x3FFCu;
+                const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff);   // :435-436
+                int32_t val = (int32_t)e >> TE_VALUE_SHIFT;
                 if (e & (TE_ESCAPE | TE_WIDE)) {
                     if (e & TE_ESCAPE) {                                    // :438
                         if (sp < esc_lds) {
@@ -442,18 +443,17 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                         }
                         ++sp;
                     } else {
-                        val = tvalues[key];
+                        val = tvalues[toff >> 2];
                         asm volatile("; wide table value from global memory %0" : "+v"(val));
                     }
                 }
-                cur_bits -= (int)(e & TE_LEN);                              // :439
-                const bool need = cur_bits <= 0;                            // :442
+                sft -= e & TE_LEN;                                          // :439
+                const bool need = sft <= 18u;                               // :442 (cur_bits <= 0)
                 const uint64_t m = __ballot(need);                          // :443
                 const uint32_t mh = (uint32_t)(m >> half_shift);
                 if (need) {                                                 // :444-449
-                    cur = nxt;
-                    nxt = ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
-                    cur_bits += 32;
+                    bits = (bits << 32) | ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
+                    sft += 32;
                 }
                 ep += __popc(mh);                                           // :450
                 if (ep >= next_cross) {
