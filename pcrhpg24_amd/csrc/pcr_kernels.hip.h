@@ -164,9 +164,15 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
             minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
         }
         if (ok && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
-            const int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
-            const int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
-            const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+            int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
+            int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
+            int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+            if (ww > 0 && wh > 0 && (int64_t)ww * wh > a.win_capacity && (int64_t)ww * wh <= 16 * (int64_t)a.win_capacity) {
+                // too large for LDS: keep the central part of the rectangle (same aspect); the rest goes the global way
+                const float sc = sqrtf((float)a.win_capacity / ((float)ww * (float)wh));
+                const int nw = max(1, (int)floorf((float)ww * sc)), nh = max(1, (int)floorf((float)wh * sc));
+                x0 += (ww - nw) / 2; y0 += (wh - nh) / 2; ww = nw; wh = nh;
+            }
             if (ww > 0 && wh > 0 && ww * wh <= a.win_capacity && x0 < 65536 && y0 < 65536)
                 wr = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)ww | ((uint32_t)wh << 16));
         }
