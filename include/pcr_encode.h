@@ -90,6 +90,15 @@ int pcr_table_from_dict(const int32_t *dict_symbols, const uint32_t *dict_cw, co
 /* BC1-encode 16 colours (0x00BBGGRR) into 8 bytes, 4-colour mode only. */
 void pcr_bc1_encode_block(const uint32_t *colors16, uint8_t *out8);
 
+/* 10-10-10 three-level quantisation of the `loop_las_cuda` method: what the reference's loader shader produces
+ * (modules/compute/computeLasLoader.cs:147-190 getPoint, 193-252 computeBoundingBox, 255-357 processPoints), for
+ * workgroups of 1024 x 64 points as its CUDA renderer expects (modules/compute/Resources.h:4-8): point (batch b,
+ * iteration i, lane t) lives at index b*65536 + i*1024 + t of every array. Points are taken in input order.
+ * Outputs are caller-allocated: batches[ceil(n/65536)], xyz12/xyz8/xyz4/rgba[ceil(n/65536)*65536] (unused slots 0). */
+int pcr_las_quantize(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color, int64_t n,
+                     const pcr_las_info *las, pcr_xyz_batch *batches, uint32_t *xyz12, uint32_t *xyz8,
+                     uint32_t *xyz4, uint32_t *rgba, int nthreads);
+
 /* Camera matrices as the reference builds them (include/OrbitControls.h:116-134, include/Camera.h:18-38,
  * modules/huffman_hqs/huffman_hqs.h:157-183): orbit (yaw, pitch, radius, target) -> world -> view =
  * inverse(world), proj = perspective(fovy, aspect, near, far) in double, narrowed to float, then

@@ -90,6 +90,30 @@ int pcr_render_hqs_color(pcr_ctx *ctx, const pcr_render_params *p);
 int pcr_resolve_basic(pcr_ctx *ctx, const pcr_render_params *p);
 int pcr_resolve_hqs(pcr_ctx *ctx, const pcr_render_params *p);
 
+/* ---- the 10-10-10 method: ComputeLasData + ComputeLoopLasCUDA ("loop_las_cuda") ---------------------
+ * pcr_las_begin   <- ComputeLasData::load buffer creation (modules/compute/ComputeLasLoader.cpp:14-38): the batch
+ *                    table and the four 4-byte-per-point arrays (three 10-10-10 levels + colour) for
+ *                    ceil(num_points/65536) batches, zero-filled.
+ * pcr_las_upload  <- ComputeLasData::process: upload + quantisation dispatch (ComputeLasLoader.cpp:140-262, computeLasLoader.cs):
+ *                    `count` batches starting at first_batch, already quantised (pcr_las_quantize, pcr_encode.h);
+ *                    batches arrive in index order. Arrays are borrowed for the call.
+ * pcr_las_unload  <- ComputeLasData::unload (ComputeLasLoader.cpp:114-131).
+ * pcr_render_las  <- cuLaunchKernel(renderProg) of ComputeLoopLasCUDA::render (modules/compute_loop_las_cuda/
+ *                    compute_loop_las_cuda.h:164-182; kernel render.cu:130-442): one workgroup per loaded batch, the
+ *                    last one does not draw (render.cu:201-202). Keys are depth<<32 | point index.
+ * pcr_resolve_las <- the resolve launch (compute_loop_las_cuda.h:185-207; kernel resolve.cu): pixel <- colour of the
+ *                    winning point index, background 0x00443322; all pixels (the reference skips partial 16x16 tiles).
+ * pcr_las_algorithmic_bytes: HBM bytes the last pcr_render_las had to read at least once (4/8/12 B per point by
+ *                    level + 64 B per drawn batch); synchronises. */
+int     pcr_las_begin(pcr_ctx *ctx, int64_t num_points);
+int     pcr_las_upload(pcr_ctx *ctx, int64_t first_batch, int64_t count, const pcr_xyz_batch *batches,
+                       const uint32_t *xyz12, const uint32_t *xyz8, const uint32_t *xyz4, const uint32_t *rgba);
+int     pcr_las_unload(pcr_ctx *ctx);
+int64_t pcr_las_batches_loaded(const pcr_ctx *ctx);
+int     pcr_render_las(pcr_ctx *ctx, const pcr_render_params *p);
+int     pcr_resolve_las(pcr_ctx *ctx, const pcr_render_params *p);
+int64_t pcr_las_algorithmic_bytes(pcr_ctx *ctx);
+
 /* Counters of the most recent render call (synchronises). */
 int pcr_get_stats(pcr_ctx *ctx, pcr_render_stats *out);
 

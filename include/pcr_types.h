@@ -60,6 +60,16 @@ typedef struct pcr_gpu_batch {
     int64_t max_cw_len;              /* 12 */
 } pcr_gpu_batch;
 
+/* struct XYZBatch of the 10-10-10 path (modules/compute_loop_las_cuda/kernel_data.h:4-22, 64 bytes): bounding box of
+ * the batch relative to the cloud's box minimum, and how many of its 65 536 slots hold real points. */
+typedef struct pcr_xyz_batch {
+    int32_t state;
+    float   min_x, min_y, min_z;
+    float   max_x, max_y, max_z;
+    int32_t num_points;
+    int32_t padding[8];
+} pcr_xyz_batch;
+
 /* First 40 bytes of a .huffman file. */
 typedef struct pcr_file_header {
     int64_t num_points;      /* after padding; multiple of 65536 */

@@ -466,6 +466,88 @@ void pcr_oracle_resolve_hqs(const pcr_render_params *p, const uint64_t *fb,
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * 10-10-10 path: modules/compute_loop_las_cuda/render.cu
+ * ---------------------------------------------------------------------------------------------- */
+int pcr_oracle_las_level(const pcr_xyz_batch *b, const pcr_render_params *p)
+{
+    const float bmin[3] = { b->min_x, b->min_y, b->min_z }, bmax[3] = { b->max_x, b->max_y, b->max_z };
+    if (p->enable_frustum_culling && !intersects_frustum(p, bmin, bmax)) return -1;   /* render.cu:153-155 */
+    /* :157-186, same expressions as the Huffman kernels' LOD block */
+    f4 ctr = { 0.5f * (bmin[0] + bmax[0]), 0.5f * (bmin[1] + bmax[1]), 0.5f * (bmin[2] + bmax[2]), 1.0f };
+    float dx = bmin[0] - bmax[0], dy = bmin[1] - bmax[1], dz = bmin[2] - bmax[2];
+    float rad = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    f4 vc = mat_mul(p->world_view, ctr);
+    f4 ve = { vc.x + rad, vc.y + 0.0f, vc.z + 0.0f, vc.w + 0.0f };
+    f4 pc = mat_mul(p->proj, vc), pe = mat_mul(p->proj, ve);
+    float fw = (float)p->width, fh = (float)p->height;
+    float scx = fw * (0.5f * (pc.x / pc.w + 1.0f)), scy = fh * (0.5f * (pc.y / pc.w + 1.0f));
+    float sex = fw * (0.5f * (pe.x / pe.w + 1.0f)), sey = fh * (0.5f * (pe.y / pe.w + 1.0f));
+    float ddx = sex - scx, ddy = sey - scy;
+    float px = sqrtf(fmaf(ddy, ddy, ddx * ddx));
+    if (px < 100.0f) return 4;            /* :187-197 */
+    if (px < 200.0f) return 3;
+    if (px < 500.0f) return 2;
+    if (px < 10000.0f) return 1;
+    return 0;
+}
+
+void pcr_oracle_render_las(const pcr_xyz_batch *batches, int64_t num_batches, const uint32_t *xyz12,
+                           const uint32_t *xyz8, const uint32_t *xyz4, const pcr_render_params *p,
+                           uint64_t *fb, pcr_render_stats *stats)
+{
+    const size_t fb_elems = pcr_fb_elems(p->width, p->height);
+    for (int64_t b = 0; b < num_batches; ++b) {
+        const pcr_xyz_batch *g = &batches[b];
+        if (stats) stats->batches_total++;
+        int level = pcr_oracle_las_level(g, p);
+        if (level < 0) { if (stats) stats->batches_culled++; continue; }
+        if (b == num_batches - 1) continue;                       /* render.cu:201-202 */
+        if (stats) stats->points_iterated += PCR_POINTS_PER_BATCH;
+        const float bs[3] = { g->max_x - g->min_x, g->max_y - g->min_y, g->max_z - g->min_z };   /* :145 */
+        const float lo[3] = { g->min_x, g->min_y, g->min_z };
+        const float div = level >= 2 ? 1024.0f : 1073741824.0f;  /* STEPS_10BIT / STEPS_30BIT */
+        const float sc[3] = { bs[0] / div, bs[1] / div, bs[2] / div };
+        for (int64_t k = 0; k < PCR_POINTS_PER_BATCH; ++k) {
+            const uint32_t index = (uint32_t)(b * PCR_POINTS_PER_BATCH + k);   /* :331 */
+            uint32_t X, Y, Z;
+            const uint32_t b4 = xyz4[index];
+            if (level >= 2) {                                      /* :381-392 */
+                X = b4 & 1023u; Y = (b4 >> 10) & 1023u; Z = (b4 >> 20) & 1023u;
+            } else {
+                const uint32_t b8 = xyz8[index];
+                X = ((b4 & 1023u) << 20) | ((b8 & 1023u) << 10);
+                Y = (((b4 >> 10) & 1023u) << 20) | (((b8 >> 10) & 1023u) << 10);
+                Z = (((b4 >> 20) & 1023u) << 20) | (((b8 >> 20) & 1023u) << 10);
+                if (level == 0) {                                  /* :333-356 */
+                    const uint32_t b12 = xyz12[index];
+                    X |= b12 & 1023u; Y |= (b12 >> 10) & 1023u; Z |= (b12 >> 20) & 1023u;
+                }
+            }
+            f4 pt = { fmaf((float)X, sc[0], lo[0]), fmaf((float)Y, sc[1], lo[1]), fmaf((float)Z, sc[2], lo[2]), 1.0f };
+            /* rasterize, render.cu:108-128 */
+            f4 pos = mat_mul(p->transform, pt);
+            float nx = pos.x / pos.w, ny = pos.y / pos.w;
+            if (!(pos.w > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f)) continue;
+            float ix = fmaf(nx, 0.5f, 0.5f) * (float)p->width, iy = fmaf(ny, 0.5f, 0.5f) * (float)p->height;
+            int64_t pix = (int64_t)(int)ix + (int64_t)(int)iy * p->width;
+            if (pix < 0 || (size_t)pix >= fb_elems) continue;
+            uint64_t key = ((uint64_t)f32_bits(pos.w) << 32) | index;
+            if (key < fb[pix]) fb[pix] = key;
+        }
+    }
+}
+
+void pcr_oracle_resolve_las(const pcr_render_params *p, const uint64_t *fb, const uint32_t *rgba_points,
+                            uint32_t *rgba)
+{
+    /* resolve.cu: every pixel (the reference launches floor(w/16) x floor(h/16) tiles and leaves the rest untouched) */
+    for (int i = 0; i < p->width * p->height; ++i) {
+        uint32_t id = (uint32_t)fb[i];
+        rgba[i] = id < 0x7FFFFFFFu ? rgba_points[id] : PCR_BACKGROUND_COLOR;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Scalar per-chain decoder: include/huffman.h:433-477 (decompress_udtype_subarray_fast_pjn_idea)
  * ---------------------------------------------------------------------------------------------- */
 void pcr_oracle_decode_chain(const uint32_t *words, int64_t num_words, const int32_t *separate,

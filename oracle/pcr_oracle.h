@@ -75,6 +75,18 @@ void pcr_oracle_resolve_basic(const pcr_render_params *p, const uint64_t *fb, ui
 void pcr_oracle_resolve_hqs(const pcr_render_params *p, const uint64_t *fb,
                             const uint64_t *rg, const uint64_t *ba, uint32_t *rgba);
 
+/* ---- 10-10-10 path: modules/compute_loop_las_cuda/render.cu:130-442 (non-prefetch loop) + resolve.cu -------------
+ * Buffers as the reference's ComputeLasData holds them: point (batch b, iteration i, lane t) at b*65536 + i*1024 + t.
+ * PARITY UNPINNED (no reference vectors; the method is disabled in the reference's main.cpp). The reference kernel
+ * skips its last workgroup (render.cu:201-202); reproduced. fb key = depth<<32 | point index. */
+void pcr_oracle_render_las(const pcr_xyz_batch *batches, int64_t num_batches, const uint32_t *xyz12,
+                           const uint32_t *xyz8, const uint32_t *xyz4, const pcr_render_params *p,
+                           uint64_t *fb, pcr_render_stats *stats);
+/* 0: full 30 bit, 1: 20 bit, 2..4: 10 bit; -1: culled. (render.cu:153-197) */
+int pcr_oracle_las_level(const pcr_xyz_batch *b, const pcr_render_params *p);
+void pcr_oracle_resolve_las(const pcr_render_params *p, const uint64_t *fb, const uint32_t *rgba_points,
+                            uint32_t *rgba);
+
 /* Per-chain scalar table decoder (include/huffman.h:433-477), used to pin table semantics. */
 void pcr_oracle_decode_chain(const uint32_t *words, int64_t num_words, const int32_t *separate,
                              const int32_t *dt_values, const int32_t *dt_cwlen,

@@ -21,6 +21,11 @@ class GpuBatch(C.Structure):                      # include/pcr_types.h: pcr_gpu
                                      "cluster_sizes_offset", "max_cw_len")]
 
 
+class XyzBatch(C.Structure):                      # pcr_xyz_batch (kernel_data.h:4-22)
+    _fields_ = [("state", c_i32)] + [(n, c_f32) for n in ("min_x", "min_y", "min_z", "max_x", "max_y", "max_z")] + \
+               [("num_points", c_i32), ("padding", c_i32 * 8)]
+
+
 class FileHeader(C.Structure):                    # pcr_file_header
     _fields_ = [(n, c_i64) for n in ("num_points", "num_batches", "encoded_bytes", "separate_bytes", "cluster_bytes")]
 
@@ -56,7 +61,7 @@ class EncodeStats(C.Structure):                   # pcr_encode_stats
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-assert C.sizeof(GpuBatch) == 160 and C.sizeof(FileHeader) == 40 and C.sizeof(RenderParams) == 224
+assert C.sizeof(XyzBatch) == 64 and C.sizeof(GpuBatch) == 160 and C.sizeof(FileHeader) == 40 and C.sizeof(RenderParams) == 224
 
 
 def fb_elems(w: int, h: int) -> int:
@@ -71,12 +76,14 @@ HIP_SYMBOLS = [
     "pcr_read_accum", "pcr_read_rgba", "pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba",
     "pcr_use_external_buffers", "pcr_merge_min", "pcr_merge_sum", "pcr_flip_sign", "pcr_timing_begin",
     "pcr_timing_end", "pcr_stream_algorithmic_bytes",
+    "pcr_las_begin", "pcr_las_upload", "pcr_las_unload", "pcr_las_batches_loaded", "pcr_render_las", "pcr_resolve_las",
+    "pcr_las_algorithmic_bytes",
 ]
 
 HOST_SYMBOLS = [
     "pcr_host_last_error", "pcr_host_free", "pcr_encode_points", "pcr_synth_points", "pcr_synth_las_info",
     "pcr_synth_encode", "pcr_morton_key", "pcr_huffman_build", "pcr_pack_chain", "pcr_table_from_dict",
-    "pcr_bc1_encode_block", "pcr_camera_orbit",
+    "pcr_bc1_encode_block", "pcr_las_quantize", "pcr_camera_orbit",
 ]
 
 _hip = None
@@ -97,7 +104,8 @@ def hip_lib() -> C.CDLL:
         lib.pcr_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         lib.pcr_destroy.argtypes = [C.c_void_p]
         lib.pcr_destroy.restype = None
-        for n in ("pcr_batches_loaded", "pcr_points_loaded", "pcr_stream_algorithmic_bytes"):
+        for n in ("pcr_batches_loaded", "pcr_points_loaded", "pcr_stream_algorithmic_bytes", "pcr_las_batches_loaded",
+                  "pcr_las_algorithmic_bytes"):
             getattr(lib, n).restype = c_i64
             getattr(lib, n).argtypes = [C.c_void_p]
         for n in ("pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba"):
@@ -114,6 +122,11 @@ def hip_lib() -> C.CDLL:
         lib.pcr_clear.argtypes = [C.c_void_p]
         for n in ("pcr_render_basic", "pcr_render_hqs_depth", "pcr_render_hqs_color", "pcr_resolve_basic", "pcr_resolve_hqs"):
             getattr(lib, n).argtypes = [C.c_void_p, C.POINTER(RenderParams)]
+        for n in ("pcr_render_las", "pcr_resolve_las"):
+            getattr(lib, n).argtypes = [C.c_void_p, C.POINTER(RenderParams)]
+        lib.pcr_las_begin.argtypes = [C.c_void_p, c_i64]
+        lib.pcr_las_upload.argtypes = [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pcr_las_unload.argtypes = [C.c_void_p]
         lib.pcr_get_stats.argtypes = [C.c_void_p, C.POINTER(RenderStats)]
         lib.pcr_read_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.pcr_read_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -154,6 +167,8 @@ def host_lib() -> C.CDLL:
         lib.pcr_table_from_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p]
         lib.pcr_bc1_encode_block.argtypes = [C.c_void_p, C.c_void_p]
         lib.pcr_bc1_encode_block.restype = None
+        lib.pcr_las_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.POINTER(LasInfo), C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.pcr_camera_orbit.argtypes = [c_f64, c_f64, c_f64, C.POINTER(c_f64), C.c_int, C.c_int, c_f64, c_f64, c_f64,
                                          C.POINTER(RenderParams)]
         _host = lib

@@ -70,13 +70,14 @@ def build_tools(force: bool = False) -> None:
     and pcr_preprocess (the reference's preprocess CLI)."""
     build_host(force)
     build_hip(force)
-    rsrc = [os.path.join(CSRC, "pcr_render.cpp"), os.path.join(CSRC, "pcr_methods.hpp"), HIP_LIB, HOST_LIB]
+    rsrc = [os.path.join(CSRC, "pcr_render.cpp"), os.path.join(CSRC, "pcr_methods.hpp"), os.path.join(CSRC, "pcr_las_reader.hpp"),
+            HIP_LIB, HOST_LIB]
     if force or _stale(RENDER_BIN, rsrc):
         _run([_hipcc(), "-O2", "-std=c++17", "-I", INCLUDE, "-I", CSRC, rsrc[0], "-o", RENDER_BIN,
               "-L", PKG_DIR, "-lpcr_hip", "-lpcr_host", "-lpthread", "-Wl,-rpath,$ORIGIN"])
-    psrc = [os.path.join(CSRC, "pcr_preprocess.cpp"), HOST_LIB]
+    psrc = [os.path.join(CSRC, "pcr_preprocess.cpp"), os.path.join(CSRC, "pcr_las_reader.hpp"), HOST_LIB]
     if force or _stale(PREPROCESS_BIN, psrc):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INCLUDE, psrc[0], "-o", PREPROCESS_BIN,
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", CSRC, psrc[0], "-o", PREPROCESS_BIN,
               "-L", PKG_DIR, "-lpcr_host", "-lpthread", "-Wl,-rpath,$ORIGIN"])
 
 

@@ -48,6 +48,14 @@ struct pcr_ctx {
     bool arena_busy[2] = {false, false};
     int arena_next = 0;
 
+    // resource of the 10-10-10 path (ComputeLasData)
+    bool las_open = false;
+    int64_t las_capacity = 0, las_loaded = 0;   // batches
+    pcr_xyz_batch *d_xyzb = nullptr;
+    uint32_t *d_xyz12 = nullptr, *d_xyz8 = nullptr, *d_xyz4 = nullptr, *d_point_rgba = nullptr;
+    int32_t *d_las_level = nullptr;
+    uint2 *d_las_win = nullptr;
+
     // method (framebuffers)
     int width = 0, height = 0;
     size_t fb_elems = 0;
@@ -86,6 +94,13 @@ void free_stream_buffers(pcr_ctx *c)
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
+}
+
+void free_las_buffers(pcr_ctx *c)
+{
+    dfree(c->d_xyzb); dfree(c->d_xyz12); dfree(c->d_xyz8); dfree(c->d_xyz4); dfree(c->d_point_rgba);
+    dfree(c->d_las_level); dfree(c->d_las_win);
+    c->las_open = false; c->las_capacity = c->las_loaded = 0;
 }
 
 void free_frame_buffers(pcr_ctx *c)
@@ -188,6 +203,7 @@ void pcr_destroy(pcr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_stream_buffers(c);
+    free_las_buffers(c);
     free_frame_buffers(c);
     dfree(c->d_stats);
     for (int i = 0; i < 2; ++i) {
@@ -470,6 +486,121 @@ int pcr_render_hqs_color(pcr_ctx *c, const pcr_render_params *p)
     if (c && (!c->rg || !c->ba)) return set_err(c, PCR_E_ARG, "no RG/BA accumulation buffers");
     if (c) c->accum_dirty = true;
     return launch_render<MODE_HQS_COLOR>(c, p);
+}
+
+// ---- 10-10-10 path ------------------------------------------------------------------------------
+int pcr_las_begin(pcr_ctx *c, int64_t num_points)
+{
+    if (!c) return PCR_E_ARG;
+    if (num_points <= 0) return set_err(c, PCR_E_ARG, "num_points must be > 0");
+    const int64_t nB = (num_points + PCR_POINTS_PER_BATCH - 1) / PCR_POINTS_PER_BATCH;
+    if (nB * PCR_POINTS_PER_BATCH >= 0x7FFFFFFFll)         // the framebuffer key holds a 31-bit point index (resolve.cu)
+        return set_err(c, PCR_E_ARG, "%lld points exceed the 31-bit point index of the 10-10-10 framebuffer", (long long)num_points);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_las_buffers(c);
+    const size_t slots = (size_t)nB * PCR_POINTS_PER_BATCH;
+    int rc;
+    if ((rc = dalloc_zero(c, c->d_xyzb, (size_t)nB)) || (rc = dalloc_zero(c, c->d_xyz12, slots)) ||
+        (rc = dalloc_zero(c, c->d_xyz8, slots)) || (rc = dalloc_zero(c, c->d_xyz4, slots)) ||
+        (rc = dalloc_zero(c, c->d_point_rgba, slots)) || (rc = dalloc_zero(c, c->d_las_level, (size_t)nB)) ||
+        (rc = dalloc_zero(c, c->d_las_win, (size_t)nB))) {
+        free_las_buffers(c);
+        return rc == PCR_E_HIP ? set_err(c, PCR_E_NOMEM, "out of device memory for %lld batches", (long long)nB) : rc;
+    }
+    c->las_capacity = nB; c->las_loaded = 0; c->las_open = true;
+    return PCR_OK;
+}
+
+int pcr_las_upload(pcr_ctx *c, int64_t first_batch, int64_t count, const pcr_xyz_batch *batches, const uint32_t *xyz12,
+                   const uint32_t *xyz8, const uint32_t *xyz4, const uint32_t *rgba)
+{
+    if (!c) return PCR_E_ARG;
+    if (!c->las_open) return set_err(c, PCR_E_ARG, "pcr_las_begin has not been called");
+    if (!batches || !xyz12 || !xyz8 || !xyz4 || !rgba) return set_err(c, PCR_E_ARG, "NULL input array");
+    if (count <= 0 || first_batch != c->las_loaded || first_batch + count > c->las_capacity)
+        return set_err(c, PCR_E_ARG, "batches [%lld,%lld) out of order or beyond the %lld allocated (next expected %lld)",
+                       (long long)first_batch, (long long)(first_batch + count), (long long)c->las_capacity, (long long)c->las_loaded);
+    for (int64_t i = 0; i < count; ++i) {
+        const pcr_xyz_batch &g = batches[i];
+        if (!(g.min_x <= g.max_x && g.min_y <= g.max_y && g.min_z <= g.max_z) || g.num_points < 0 || g.num_points > PCR_POINTS_PER_BATCH)
+            return set_err(c, PCR_E_FORMAT, "batch %lld: bad bounding box or point count", (long long)(first_batch + i));
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t off = (size_t)first_batch * PCR_POINTS_PER_BATCH, n = (size_t)count * PCR_POINTS_PER_BATCH * 4;
+    HIP_TRY(c, hipMemcpyAsync(c->d_xyzb + first_batch, batches, (size_t)count * sizeof(pcr_xyz_batch), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_xyz12 + off, xyz12, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_xyz8 + off, xyz8, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_xyz4 + off, xyz4, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_point_rgba + off, rgba, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));             // the arrays are borrowed for the call only
+    c->las_loaded += count;
+    return PCR_OK;
+}
+
+int pcr_las_unload(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_las_buffers(c);
+    return PCR_OK;
+}
+
+int64_t pcr_las_batches_loaded(const pcr_ctx *c) { return c ? c->las_loaded : 0; }
+
+static int check_las(pcr_ctx *c, const pcr_render_params *p)
+{
+    if (!c) return PCR_E_ARG;
+    if (!p) return set_err(c, PCR_E_ARG, "render params are NULL");
+    if (!c->las_open) return set_err(c, PCR_E_ARG, "no 10-10-10 data loaded (call pcr_las_begin / pcr_las_upload)");
+    if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer (call pcr_set_image_size)");
+    if (p->width != c->width || p->height != c->height)
+        return set_err(c, PCR_E_ARG, "params image size %dx%d != framebuffer %dx%d", p->width, p->height, c->width, c->height);
+    return PCR_OK;
+}
+
+int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
+{
+    int rc = check_las(c, p);
+    if (rc) return rc;
+    const int64_t nB = c->las_loaded;
+    if (nB == 0) return PCR_OK;                                // compute_loop_las_cuda.h:107
+    LasArgs a;
+    a.p = *p;
+    a.s.batches = c->d_xyzb; a.s.xyz12 = c->d_xyz12; a.s.xyz8 = c->d_xyz8; a.s.xyz4 = c->d_xyz4; a.s.num_batches = nB;
+    a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
+    a.level = c->d_las_level; a.win = c->d_las_win; a.stats = c->d_stats; a.win_capacity = WIN_PIXELS;
+    HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream));
+    hipLaunchKernelGGL(k_las_prepass, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_las_render, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_resolve_las(pcr_ctx *c, const pcr_render_params *p)
+{
+    int rc = check_las(c, p);
+    if (rc) return rc;
+    dim3 grid((unsigned)((c->width + 15) / 16), (unsigned)((c->height + 15) / 16));
+    hipLaunchKernelGGL(k_las_resolve, grid, dim3(256), 0, c->stream, c->width, c->height, c->fb, c->d_point_rgba, c->d_rgba);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+int64_t pcr_las_algorithmic_bytes(pcr_ctx *c)
+{
+    if (!c || !c->las_open || c->las_loaded == 0) return 0;
+    std::vector<int32_t> level((size_t)c->las_loaded);
+    if (hipMemcpyAsync(level.data(), c->d_las_level, level.size() * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    int64_t bytes = 0;
+    for (int64_t b = 0; b + 1 < c->las_loaded; ++b) {         // the last workgroup does not run
+        const int l = level[(size_t)b];
+        if (l < 0) continue;
+        bytes += (int64_t)sizeof(pcr_xyz_batch) + (int64_t)PCR_POINTS_PER_BATCH * 4 * (l >= 2 ? 1 : l == 1 ? 2 : 3);
+    }
+    return bytes;
 }
 
 static int launch_resolve(pcr_ctx *c, const pcr_render_params *p, bool hqs)

@@ -703,6 +703,57 @@ int pcr_table_from_dict(const int32_t *dict_symbols, const uint32_t *dict_cw, co
     return 0;
 }
 
+int pcr_las_quantize(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color, int64_t n,
+                     const pcr_las_info *las, pcr_xyz_batch *batches, uint32_t *xyz12, uint32_t *xyz8,
+                     uint32_t *xyz4, uint32_t *rgba, int nthreads)
+{
+    if (!x || !y || !z || !color || !las || !batches || !xyz12 || !xyz8 || !xyz4 || !rgba || n <= 0) return fail("bad argument");
+    const int64_t PPB = PCR_POINTS_PER_BATCH, WG = PCR_WORKGROUP_SIZE;
+    const int64_t nb = (n + PPB - 1) / PPB;
+    const float fscale[3] = {(float)las->scale[0], (float)las->scale[1], (float)las->scale[2]};   // uScale is a vec3
+    const float fmin[3] = {(float)las->min[0], (float)las->min[1], (float)las->min[2]};           // uBoxMin is a vec3
+    return parallel_chunks(nb, nthreads, [&](int64_t b) {
+        const int64_t first = b * PPB, cnt = std::min(PPB, n - first);
+        std::vector<float> px((size_t)cnt), py((size_t)cnt), pz((size_t)cnt);
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int64_t k = 0; k < cnt; ++k) {
+            // getPoint, computeLasLoader.cs:178-180: float(double(X) * uScale + uOffset - double(uBoxMin))
+            volatile double ax = (double)x[first + k] * (double)fscale[0], ay = (double)y[first + k] * (double)fscale[1],
+                            az = (double)z[first + k] * (double)fscale[2];
+            const float fx = (float)(ax + las->offset[0] - (double)fmin[0]);
+            const float fy = (float)(ay + las->offset[1] - (double)fmin[1]);
+            const float fz = (float)(az + las->offset[2] - (double)fmin[2]);
+            px[(size_t)k] = fx; py[(size_t)k] = fy; pz[(size_t)k] = fz;
+            mn[0] = std::min(mn[0], fx); mn[1] = std::min(mn[1], fy); mn[2] = std::min(mn[2], fz);
+            mx[0] = std::max(mx[0], fx); mx[1] = std::max(mx[1], fy); mx[2] = std::max(mx[2], fz);
+        }
+        pcr_xyz_batch g{};
+        g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2]; g.max_x = mx[0]; g.max_y = mx[1]; g.max_z = mx[2];
+        g.num_points = (int32_t)cnt;                                           // processPoints :271-273
+        batches[b] = g;
+        const float size[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        auto q30 = [](float p, float lo, float sz) -> uint32_t {                // :288-294
+            if (!(sz > 0.0f)) return 0u;                                        // flat box: the shader divides 0 by 0
+            volatile float t = (p - lo) / sz;
+            volatile float u = t * 1073741824.0f;
+            uint32_t v = u >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)u;
+            return std::min(v, (uint32_t)(1073741824u - 1u));
+        };
+        for (int64_t k = 0; k < PPB; ++k) {
+            // slot k of the batch in (iteration, lane) order holds input point first + k
+            const int64_t slot = first + k;
+            if (k >= cnt) { xyz12[slot] = xyz8[slot] = xyz4[slot] = rgba[slot] = 0; continue; }
+            const uint32_t X = q30(px[(size_t)k], mn[0], size[0]), Y = q30(py[(size_t)k], mn[1], size[1]), Z = q30(pz[(size_t)k], mn[2], size[2]);
+            xyz4[slot] = ((X >> 20) & 1023u) | (((Y >> 20) & 1023u) << 10) | (((Z >> 20) & 1023u) << 20);   // :313-322
+            xyz8[slot] = ((X >> 10) & 1023u) | (((Y >> 10) & 1023u) << 10) | (((Z >> 10) & 1023u) << 20);   // :325-334
+            xyz12[slot] = (X & 1023u) | ((Y & 1023u) << 10) | ((Z & 1023u) << 20);                           // :337-346
+            rgba[slot] = color[first + k];                                      // :284
+        }
+        (void)WG;
+        return 0;
+    });
+}
+
 int pcr_camera_orbit(double yaw, double pitch, double radius, const double target[3],
                      int width, int height, double fovy_deg, double near_plane, double far_plane,
                      pcr_render_params *out)

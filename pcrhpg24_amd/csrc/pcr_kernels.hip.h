@@ -568,6 +568,211 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 10-10-10 path ("loop_las_cuda", modules/compute_loop_las_cuda/render.cu:130-442)
+//
+// Streaming kernel: one workgroup per batch of 65 536 points, thread t takes the point quads t, t+1024, ... so every
+// level buffer is read with 16-byte-per-lane loads (the reference's USE_PREFETCH uint4 idea, render.cu:204-327; the
+// point -> thread mapping is free because the result is a min over all points). Level 2..4 batches read 4 B per
+// point, level 1 reads 8 B, level 0 reads 12 B. Scatter uses the same LDS framebuffer window as the Huffman kernel.
+// ------------------------------------------------------------------------------------------------
+struct LasView {
+    const pcr_xyz_batch *batches;
+    const uint32_t *xyz12, *xyz8, *xyz4;
+    int64_t num_batches;
+};
+
+struct LasArgs {
+    pcr_render_params p;
+    LasView s;
+    FrameView f;
+    int32_t *level;           // [nB] -1 culled, 0 / 1 / 2..4
+    uint2 *win;               // [nB]
+    pcr_render_stats *stats;
+    int win_capacity;
+};
+
+__device__ __forceinline__ uint2 window_rect(const pcr_render_params &p, const float *bmin, const float *bmax, int capacity)
+{
+    float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
+    const float fw = (float)p.width, fh = (float)p.height;
+    for (int c = 0; c < 8; ++c) {
+        const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
+        const float w = dot4(p.transform + 12, x, y, z, 1.0f);
+        if (!(w > 1.0e-6f)) return make_uint2(0, 0);
+        const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
+        const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    if (!(maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f)) return make_uint2(0, 0);
+    int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
+    int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
+    int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+    if (ww > 0 && wh > 0 && (int64_t)ww * wh > capacity && (int64_t)ww * wh <= 16 * (int64_t)capacity) {
+        const float sc = sqrtf((float)capacity / ((float)ww * (float)wh));
+        const int nw = max(1, (int)floorf((float)ww * sc)), nh = max(1, (int)floorf((float)wh * sc));
+        x0 += (ww - nw) / 2; y0 += (wh - nh) / 2; ww = nw; wh = nh;
+    }
+    if (ww > 0 && wh > 0 && ww * wh <= capacity && x0 < 65536 && y0 < 65536)
+        return make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)ww | ((uint32_t)wh << 16));
+    return make_uint2(0, 0);
+}
+
+__global__ void __launch_bounds__(256) k_las_prepass(LasArgs a)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.s.num_batches) return;
+    const pcr_xyz_batch g = a.s.batches[b];
+    const pcr_render_params &p = a.p;
+    const float bmin[3] = { g.min_x, g.min_y, g.min_z }, bmax[3] = { g.max_x, g.max_y, g.max_z };
+    atomicAdd((unsigned long long *)&a.stats->batches_total, 1ull);
+    if (p.enable_frustum_culling) {                                          // render.cu:153-155
+        const float *M = p.transform;
+#define T(i) M[((i) % 4) * 4 + ((i) / 4)]
+        bool in = plane_accepts(T(3) - T(0), T(7) - T(4), T(11) - T(8),  T(15) - T(12), bmin, bmax)
+               && plane_accepts(T(3) + T(0), T(7) + T(4), T(11) + T(8),  T(15) + T(12), bmin, bmax)
+               && plane_accepts(T(3) + T(1), T(7) + T(5), T(11) + T(9),  T(15) + T(13), bmin, bmax)
+               && plane_accepts(T(3) - T(1), T(7) - T(5), T(11) - T(9),  T(15) - T(13), bmin, bmax)
+               && plane_accepts(T(3) - T(2), T(7) - T(6), T(11) - T(10), T(15) - T(14), bmin, bmax)
+               && plane_accepts(T(3) + T(2), T(7) + T(6), T(11) + T(10), T(15) + T(14), bmin, bmax);
+#undef T
+        if (!in) {
+            a.level[b] = -1;
+            atomicAdd((unsigned long long *)&a.stats->batches_culled, 1ull);
+            return;
+        }
+    }
+    // :157-197
+    const float cx = 0.5f * (bmin[0] + bmax[0]), cy = 0.5f * (bmin[1] + bmax[1]), cz = 0.5f * (bmin[2] + bmax[2]);
+    const float dx = bmin[0] - bmax[0], dy = bmin[1] - bmax[1], dz = bmin[2] - bmax[2];
+    const float rad = sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+    float vc[4], ve[4], pc[4], pe[4];
+    for (int r = 0; r < 4; ++r) vc[r] = dot4(p.world_view + 4 * r, cx, cy, cz, 1.0f);
+    ve[0] = vc[0] + rad; ve[1] = vc[1] + 0.0f; ve[2] = vc[2] + 0.0f; ve[3] = vc[3] + 0.0f;
+    for (int r = 0; r < 4; ++r) {
+        pc[r] = dot4(p.proj + 4 * r, vc[0], vc[1], vc[2], vc[3]);
+        pe[r] = dot4(p.proj + 4 * r, ve[0], ve[1], ve[2], ve[3]);
+    }
+    const float fw = (float)p.width, fh = (float)p.height;
+    const float scx = fw * (0.5f * (pc[0] / pc[3] + 1.0f)), scy = fh * (0.5f * (pc[1] / pc[3] + 1.0f));
+    const float sex = fw * (0.5f * (pe[0] / pe[3] + 1.0f)), sey = fh * (0.5f * (pe[1] / pe[3] + 1.0f));
+    const float ddx = sex - scx, ddy = sey - scy;
+    const float px = sqrtf(__fmaf_rn(ddy, ddy, ddx * ddx));
+    a.level[b] = px < 100.0f ? 4 : px < 200.0f ? 3 : px < 500.0f ? 2 : px < 10000.0f ? 1 : 0;
+    if (b != a.s.num_batches - 1)                                            // the last workgroup returns early (:201-202)
+        atomicAdd((unsigned long long *)&a.stats->points_iterated, (unsigned long long)PCR_POINTS_PER_BATCH);
+    a.win[b] = window_rect(p, bmin, bmax, a.win_capacity);
+}
+
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
+{
+    const uint32_t b = blockIdx.x;
+    const int level = a.level[b];
+    if (level < 0 || b == (uint32_t)(a.s.num_batches - 1)) return;           // :153-155, :201-202
+    const uint32_t tid = threadIdx.x;
+    __shared__ __align__(16) unsigned long long s_win[WIN_PIXELS];
+
+    const uint2 wr = a.win[b];
+    const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
+    const uint32_t wpix = ww * wh;
+    const uint32_t W = (uint32_t)a.p.width;
+    for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
+        const uint32_t y = i / ww, x = i - y * ww;
+        s_win[i] = a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
+    }
+    const pcr_xyz_batch g = a.s.batches[b];
+    const float div = level >= 2 ? 1024.0f : 1073741824.0f;                  // STEPS_10BIT / STEPS_30BIT
+    const float sx = (g.max_x - g.min_x) / div, sy = (g.max_y - g.min_y) / div, sz = (g.max_z - g.min_z) / div;   // :145, :345
+    const float *M = a.p.transform;
+    const float fw = (float)a.p.width, fh = (float)a.p.height;
+    const size_t base = (size_t)b * PCR_POINTS_PER_BATCH;
+    const uint4 *q4 = reinterpret_cast<const uint4 *>(a.s.xyz4 + base);
+    const uint4 *q8 = reinterpret_cast<const uint4 *>(a.s.xyz8 + base);
+    const uint4 *q12 = reinterpret_cast<const uint4 *>(a.s.xyz12 + base);
+    __syncthreads();
+
+    uint4 n4 = q4[tid], n8 = make_uint4(0, 0, 0, 0), n12 = make_uint4(0, 0, 0, 0);
+    if (level <= 1) n8 = q8[tid];
+    if (level == 0) n12 = q12[tid];
+    for (int i = 0; i < PCR_POINTS_PER_BATCH / 4 / PCR_WORKGROUP_SIZE; ++i) {
+        const uint4 c4 = n4, c8 = n8, c12 = n12;
+        const uint32_t quad = tid + (uint32_t)i * PCR_WORKGROUP_SIZE;
+        if (i + 1 < PCR_POINTS_PER_BATCH / 4 / PCR_WORKGROUP_SIZE) {         // next quad in flight while this one is projected
+            n4 = q4[quad + PCR_WORKGROUP_SIZE];
+            if (level <= 1) n8 = q8[quad + PCR_WORKGROUP_SIZE];
+            if (level == 0) n12 = q12[quad + PCR_WORKGROUP_SIZE];
+        }
+        const uint32_t w4[4] = { c4.x, c4.y, c4.z, c4.w }, w8[4] = { c8.x, c8.y, c8.z, c8.w }, w12[4] = { c12.x, c12.y, c12.z, c12.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t index = (uint32_t)base + quad * 4 + j;
+            uint32_t X, Y, Z;
+            if (level >= 2) {                                                // :381-392
+                X = w4[j] & 1023u; Y = (w4[j] >> 10) & 1023u; Z = (w4[j] >> 20) & 1023u;
+            } else {                                                         // :333-378
+                X = ((w4[j] & 1023u) << 20) | ((w8[j] & 1023u) << 10) | (w12[j] & 1023u);
+                Y = (((w4[j] >> 10) & 1023u) << 20) | (((w8[j] >> 10) & 1023u) << 10) | ((w12[j] >> 10) & 1023u);
+                Z = (((w4[j] >> 20) & 1023u) << 20) | (((w8[j] >> 20) & 1023u) << 10) | ((w12[j] >> 20) & 1023u);
+            }
+            const float x = __fmaf_rn((float)X, sx, g.min_x), y = __fmaf_rn((float)Y, sy, g.min_y), z = __fmaf_rn((float)Z, sz, g.min_z);
+            // rasterize (:108-128); projection as in k_render (exact inside test, shared-reciprocal division)
+            const float qx = dot4(M + 0, x, y, z, 1.0f), qy = dot4(M + 4, x, y, z, 1.0f), qw = dot4(M + 12, x, y, z, 1.0f);
+            uint32_t pix = NO_PIXEL;
+            int ix = 0, iy = 0;
+            const bool w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;
+            if (__builtin_expect(__any(!w_ok && !(qw <= 0.0f)), 0)) {
+                const float nx = qx / qw, ny = qy / qw;
+                if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {
+                    ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw); iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+                    pix = (uint32_t)(ix + iy * a.p.width);
+                    if (pix >= a.f.fb_elems) pix = NO_PIXEL;
+                }
+            } else if (w_ok && fabsf(qx) <= qw && fabsf(qy) <= qw) {
+                const float r0 = __builtin_amdgcn_rcpf(qw);
+                const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
+                const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
+                const v2f q0 = xy * rr;
+                const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
+                const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
+                const v2f half = {0.5f, 0.5f}, size = {fw, fh};
+                const v2f img = __builtin_elementwise_fma(q2, half, half) * size;
+                ix = (int)img.x; iy = (int)img.y;
+                pix = (uint32_t)(ix + iy * a.p.width);
+            }
+            if (pix != NO_PIXEL) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(qw) << 32) | index;   // :119-120
+                const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
+                if (rx < ww && ry < wh) {
+                    const uint32_t widx = ry * ww + rx;
+                    if (key < s_win[widx]) __hip_atomic_fetch_min(&s_win[widx], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (key < a.f.fb[pix]) {                              // :123-126
+                    atomicMin((unsigned long long *)&a.f.fb[pix], key);
+                }
+            }
+        }
+    }
+    if (wpix) {
+        __syncthreads();
+        for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
+            const uint32_t y = i / ww, x = i - y * ww;
+            const unsigned long long v = s_win[i];
+            unsigned long long *gp = (unsigned long long *)&a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
+            if (v < *gp) atomicMin(gp, v);
+        }
+    }
+}
+
+// modules/compute_loop_las_cuda/resolve.cu (every pixel; the reference's floor(w/16) x floor(h/16) launch skips the rest)
+__global__ void __launch_bounds__(256) k_las_resolve(int width, int height, const uint64_t *fb, const uint32_t *rgba_points,
+                                                     uint32_t *rgba)
+{
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= width || y >= height) return;
+    const int pix = x + y * width;
+    const uint32_t id = (uint32_t)fb[pix];
+    rgba[pix] = id < 0x7FFFFFFFu ? rgba_points[id] : PCR_BACKGROUND_COLOR;
+}
+
+// ------------------------------------------------------------------------------------------------
 // resolve (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
 // ------------------------------------------------------------------------------------------------
 template <bool HQS>

@@ -6,6 +6,8 @@
 //   Resource, HuffmanLasData              modules/compute/Resources.h:20-35, modules/compute/HuffmanLasLoader.{h,cpp}
 //   HuffmanMemIter ("huffman_mem_iter_cuda")   modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h
 //   HuffmanHQS     ("huffman_hqs")              modules/huffman_hqs/huffman_hqs.h
+//   ComputeLasData, ComputeLoopLasCUDA ("loop_las_cuda")   modules/compute/ComputeLasLoader.{h,cpp},
+//                                                          modules/compute_loop_las_cuda/compute_loop_las_cuda.h
 // Headless: `Renderer` carries the window size and the orbit camera only (no GLFW/GL/ImGui); the resolve target is
 // a device RGBA8 buffer instead of a GL texture.
 #pragma once
@@ -24,6 +26,7 @@
 
 #include "pcr_encode.h"
 #include "pcr_hip.h"
+#include "pcr_las_reader.hpp"
 
 namespace pcr_host {
 
@@ -272,6 +275,89 @@ struct HuffmanHQS : HuffmanMethodBase {
         r->check(pcr_render_hqs_depth(r->ctx, &lastParams), "pcr_render_hqs_depth");
         r->check(pcr_render_hqs_color(r->ctx, &lastParams), "pcr_render_hqs_color");
         r->check(pcr_resolve_hqs(r->ctx, &lastParams), "pcr_resolve_hqs");
+    }
+};
+
+// modules/compute/ComputeLasLoader.{h,cpp}: the LAS file is quantised task by task (<= 100 batches per frame, the
+// reference's MAX_POINTS_PER_BATCH load buffer) into the three 10-10-10 levels. The reference quantises in a compute
+// shader on upload (computeLasLoader.cs); here libpcr_host.so does it (pcr_las_quantize).
+struct ComputeLasData : Resource {
+    std::string path;
+    LasPoints pts;
+    int64_t numPoints = 0, numPointsLoaded = 0, numBatchesLoaded = 0;
+
+    static std::shared_ptr<ComputeLasData> create(const std::string &path)      // ComputeLasLoader.h:97-103
+    {
+        auto d = std::make_shared<ComputeLasData>();
+        d->path = path;
+        std::string err;
+        if (!read_las(path, d->pts, err)) throw std::runtime_error(err);
+        d->numPoints = d->pts.numPoints;
+        return d;
+    }
+
+    void load(Renderer *renderer) override                                       // ComputeLasLoader.cpp:14-38
+    {
+        if (state != UNLOADED) return;
+        state = LOADING;
+        renderer->check(pcr_las_begin(renderer->ctx, numPoints), "pcr_las_begin");
+        numPointsLoaded = numBatchesLoaded = 0;
+    }
+
+    void process(Renderer *renderer) override                                    // ComputeLasLoader.cpp:140-262
+    {
+        if (state != LOADING) return;
+        const int64_t first = numPointsLoaded, n = std::min<int64_t>(numPoints - first, PCR_DEFAULT_CHUNK_POINTS);
+        const int64_t nb = (n + PCR_POINTS_PER_BATCH - 1) / PCR_POINTS_PER_BATCH;
+        const size_t slots = (size_t)nb * PCR_POINTS_PER_BATCH;
+        std::vector<pcr_xyz_batch> batches((size_t)nb);
+        std::vector<uint32_t> xyz12(slots), xyz8(slots), xyz4(slots), rgba(slots);
+        if (pcr_las_quantize(pts.x.data() + first, pts.y.data() + first, pts.z.data() + first, pts.color.data() + first, n,
+                             &pts.las, batches.data(), xyz12.data(), xyz8.data(), xyz4.data(), rgba.data(), 0))
+            throw std::runtime_error(std::string("pcr_las_quantize: ") + pcr_host_last_error());
+        renderer->check(pcr_las_upload(renderer->ctx, numBatchesLoaded, nb, batches.data(), xyz12.data(), xyz8.data(),
+                                       xyz4.data(), rgba.data()), "pcr_las_upload");
+        numPointsLoaded += n;
+        numBatchesLoaded = pcr_las_batches_loaded(renderer->ctx);
+        if (numPointsLoaded == numPoints) state = LOADED;
+    }
+
+    void unload(Renderer *renderer) override                                     // ComputeLasLoader.cpp:114-131
+    {
+        numPointsLoaded = numBatchesLoaded = 0;
+        pcr_las_unload(renderer->ctx);
+        state = UNLOADED;
+    }
+
+    bool fullyLoaded() const { return numPointsLoaded == numPoints; }
+};
+
+struct ComputeLoopLasCUDA : Method {                                             // compute_loop_las_cuda.h:52-222
+    std::shared_ptr<ComputeLasData> las;
+    Renderer *renderer;
+    pcr_render_params lastParams{};
+    ComputeLoopLasCUDA(Renderer *r, std::shared_ptr<ComputeLasData> l) : las(std::move(l)), renderer(r)
+    {
+        name = "loop_las_cuda";
+        description = "- Each thread renders X points.\n- Loads points from LAS file\n- Workgroup picks 4, 8, or 12 byte precision\n  depending on screen size of bounding box";
+        group = "10-10-10 bit encoded";
+    }
+    void update(Renderer *r) override        // empty in the reference (:92-93); resource switch as huffman_hqs.h:116-124
+    {
+        if (Runtime::resource != (Resource *)las.get()) {
+            if (Runtime::resource != nullptr) Runtime::resource->unload(r);
+            las->load(r);
+            Runtime::resource = (Resource *)las.get();
+        }
+    }
+    void render(Renderer *r) override                                            // compute_loop_las_cuda.h:99-222
+    {
+        las->process(r);
+        if (las->numPointsLoaded == 0) return;
+        lastParams = r->params();
+        r->check(pcr_clear(r->ctx), "pcr_clear");
+        r->check(pcr_render_las(r->ctx, &lastParams), "pcr_render_las");
+        r->check(pcr_resolve_las(r->ctx, &lastParams), "pcr_resolve_las");
     }
 };
 

@@ -1,7 +1,8 @@
-// pcr_render — headless twin of the reference's src/main.cpp for the Huffman methods: create the renderer, the
-// HuffmanLasData resource and both methods, select one by name, then run update()/render() frames.
+// pcr_render — headless twin of the reference's src/main.cpp for the Huffman methods and the 10-10-10 method: create
+// the renderer, the resource and its methods, select one by name, then run update()/render() frames.
 //
 //   pcr_render <file.huffman> [--method huffman_mem_iter_cuda|huffman_hqs] [--size WxH]
+//   pcr_render <file.las>      --method loop_las_cuda                      [--size WxH]
 //              [--camera yaw pitch radius tx ty tz] [--lod 0.1] [--cull 0|1] [--frames N]
 //              [--dump-fb fb.u64] [--dump-rgba out.ppm]
 // Prints one JSON line: batches, frames needed to load, ms of the last frame, FNV-1a of the u64 framebuffer.
@@ -47,11 +48,20 @@ int main(int argc, char **argv)
         renderer.yaw = cam[0]; renderer.pitch = cam[1]; renderer.radius = cam[2];
         renderer.target[0] = cam[3]; renderer.target[1] = cam[4]; renderer.target[2] = cam[5];
 
-        auto las_huffman = HuffmanLasData::create(path);                // main.cpp:244
-        HuffmanMemIter huffman_mem_iter_cuda(&renderer, las_huffman);   // main.cpp:266-267
-        HuffmanHQS huffman_hqs(&renderer, las_huffman);
-        Runtime::addMethod(&huffman_mem_iter_cuda);                     // main.cpp:272-273
-        Runtime::addMethod(&huffman_hqs);
+        std::shared_ptr<HuffmanLasData> las_huffman;
+        std::shared_ptr<ComputeLasData> las_compute;
+        std::unique_ptr<Method> m0, m1;
+        if (method == "loop_las_cuda") {
+            las_compute = ComputeLasData::create(path);                 // main.cpp:241 (commented out there)
+            m0 = std::make_unique<ComputeLoopLasCUDA>(&renderer, las_compute);   // main.cpp:251 (commented out there)
+            Runtime::addMethod(m0.get());
+        } else {
+            las_huffman = HuffmanLasData::create(path);                 // main.cpp:244
+            m0 = std::make_unique<HuffmanMemIter>(&renderer, las_huffman);   // main.cpp:266-267
+            m1 = std::make_unique<HuffmanHQS>(&renderer, las_huffman);
+            Runtime::addMethod(m0.get());                               // main.cpp:272-273
+            Runtime::addMethod(m1.get());
+        }
         Runtime::setSelectedMethod(method);
         Method *selected = Runtime::getSelectedMethod();
         if (!selected) { std::fprintf(stderr, "no method named %s\n", method.c_str()); return 2; }
@@ -66,7 +76,7 @@ int main(int argc, char **argv)
             renderer.check(pcr_synchronize(renderer.ctx), "pcr_synchronize");
             ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             ++n;
-            bool loaded = las_huffman->fullyLoaded();
+            bool loaded = las_huffman ? las_huffman->fullyLoaded() : las_compute->fullyLoaded();
             if (frames > 0 ? n >= frames && loaded : loaded) break;
             if (n > 100000) throw std::runtime_error("loader made no progress");
         }
@@ -88,7 +98,7 @@ int main(int argc, char **argv)
         }
         std::printf("{\"method\": \"%s\", \"batches\": %lld, \"frames_to_load\": %d, \"last_frame_ms\": %.3f, \"points_iterated\": %lld, "
                     "\"batches_culled\": %lld, \"covered_pixels\": %zu, \"fb_fnv1a\": \"%016llx\"}\n",
-                    selected->name.c_str(), (long long)las_huffman->numBatches, n, ms, (long long)st.points_iterated,
+                    selected->name.c_str(), (long long)(las_huffman ? las_huffman->numBatches : las_compute->numBatchesLoaded), n, ms, (long long)st.points_iterated,
                     (long long)st.batches_culled, covered, (unsigned long long)fnv1a(fb.data(), fb.size() * 8));
         Runtime::resource->unload(&renderer);
     } catch (const std::exception &e) {

@@ -8,6 +8,8 @@ of the reference viewer without a window:
     HuffmanLasData.create(path)                                                  modules/compute/HuffmanLasLoader.h:87-92
     HuffmanMemIter  ("huffman_mem_iter_cuda")                                    modules/huffman_mem_iter_cuda/huffman_mem_iter_cuda.h
     HuffmanHQS      ("huffman_hqs")                                              modules/huffman_hqs/huffman_hqs.h
+    ComputeLasData.create(path) / ComputeLoopLasCUDA ("loop_las_cuda")           modules/compute/ComputeLasLoader.{h,cpp},
+                                                                                 modules/compute_loop_las_cuda/compute_loop_las_cuda.h
     Runtime.addMethod / setSelectedMethod / resource                             include/Runtime.h:15-55
     Debug.LOD / frustumCullingEnabled / colorizeChunks / showNumPoints           include/Debug.h:14-31
 
@@ -25,7 +27,7 @@ from typing import Iterator, Optional
 import numpy as np
 
 from . import _native as N
-from ._native import EncodeStats, FileHeader, LasInfo, RenderParams, RenderStats, fb_elems
+from ._native import EncodeStats, FileHeader, LasInfo, RenderParams, RenderStats, XyzBatch, fb_elems
 
 POINTS_PER_BATCH = 65536
 ENCODED_PAD_WORDS = 1024
@@ -122,6 +124,55 @@ def camera_orbit(yaw: float, pitch: float, radius: float, target, width: int, he
 # --------------------------------------------------------------------------------------------------
 # .huffman container (HuffmanLasData::loadHeader, HuffmanLasLoader.h:57-85)
 # --------------------------------------------------------------------------------------------------
+def las_quantize(x, y, z, color, las: LasInfo, nthreads: int = 0):
+    """10-10-10 three-level quantisation of points in input order (pcr_las_quantize): returns
+    (batches[nB] XyzBatch array, xyz12, xyz8, xyz4, rgba) with nB*65536 slots each."""
+    x, y, z = (np.ascontiguousarray(a, np.int32) for a in (x, y, z))
+    color = np.ascontiguousarray(color, np.uint32)
+    n = len(x)
+    if not (len(y) == len(z) == len(color) == n) or n == 0:
+        raise ValueError("x, y, z, color must be non-empty and of equal length")
+    nb = (n + POINTS_PER_BATCH - 1) // POINTS_PER_BATCH
+    batches = (XyzBatch * nb)()
+    arrs = [np.empty(nb * POINTS_PER_BATCH, np.uint32) for _ in range(4)]
+    rc = N.host_lib().pcr_las_quantize(x.ctypes.data, y.ctypes.data, z.ctypes.data, color.ctypes.data, n, C.byref(las),
+                                       C.addressof(batches), *(a.ctypes.data for a in arrs), nthreads)
+    if rc:
+        raise PcrError(f"pcr_las_quantize failed: {N.host_error()}")
+    return (batches, *arrs)
+
+
+def read_las(path: str):
+    """Minimal LAS 1.x reader for the loaders (header fields and point layout as ComputeLasData::loadHeader reads
+    them, modules/compute/ComputeLasLoader.h:55-95, and getPoint, computeLasLoader.cs:147-190): returns
+    (x, y, z int32, color 0x00BBGGRR uint32, LasInfo)."""
+    with open(path, "rb") as f:
+        hdr = f.read(375)
+        if len(hdr) < 227 or hdr[:4] != b"LASF":
+            raise PcrError(f"{path}: not a LAS file")
+        major, minor = hdr[24], hdr[25]
+        n = struct.unpack_from("<I", hdr, 107)[0] if (major == 1 and minor < 4) else struct.unpack_from("<Q", hdr, 247)[0]
+        n = min(n, 1_000_000_000)                                     # ComputeLasLoader.h:69
+        off, fmt, bpp = struct.unpack_from("<I", hdr, 96)[0], hdr[104], struct.unpack_from("<H", hdr, 105)[0]
+        las = LasInfo()
+        sc = struct.unpack_from("<6d", hdr, 131)
+        las.scale[:], las.offset[:] = sc[:3], sc[3:]
+        mx_x, mn_x, mx_y, mn_y, mx_z, mn_z = struct.unpack_from("<6d", hdr, 179)
+        las.min[:], las.max[:] = (mn_x, mn_y, mn_z), (mx_x, mx_y, mx_z)
+        f.seek(off)
+        raw = np.frombuffer(f.read(n * bpp), np.uint8)
+    if len(raw) != n * bpp:
+        raise PcrError(f"{path}: truncated point data")
+    raw = raw.reshape(n, bpp)
+    xyz = np.ascontiguousarray(raw[:, :12]).view("<i4")
+    off_rgb = {2: 20, 3: 28, 7: 30, 8: 30}.get(fmt % 128, 0)         # computeLasLoader.cs:151-160 (0: reads X's bytes)
+    rgb = np.ascontiguousarray(raw[:, off_rgb:off_rgb + 6]).view("<u2").astype(np.uint32)
+    rgb = np.where(rgb > 255, rgb // 256, rgb)                       # :170-172
+    color = rgb[:, 0] | (rgb[:, 1] << 8) | (rgb[:, 2] << 16)
+    return (np.ascontiguousarray(xyz[:, 0]), np.ascontiguousarray(xyz[:, 1]), np.ascontiguousarray(xyz[:, 2]),
+            color.astype(np.uint32), las)
+
+
 class HuffmanFile:
     """Header + batch-record slicing of a .huffman image held in memory or memory-mapped from disk."""
 
@@ -252,6 +303,35 @@ class Context:
         return int(self.lib.pcr_stream_algorithmic_bytes(self.h))
 
     # method side
+    # -- 10-10-10 resource / method ----------------------------------------------------------------
+    def las_begin(self, num_points: int):
+        self._chk(self.lib.pcr_las_begin(self.h, num_points), "pcr_las_begin")
+
+    def las_upload(self, first_batch: int, batches, xyz12, xyz8, xyz4, rgba) -> None:
+        count = len(batches)
+        for a in (xyz12, xyz8, xyz4, rgba):
+            if a.dtype != np.uint32 or not a.flags.c_contiguous or len(a) != count * POINTS_PER_BATCH:
+                raise ValueError("level arrays must be contiguous uint32 with 65536 slots per batch")
+        self._chk(self.lib.pcr_las_upload(self.h, first_batch, count, C.addressof(batches), xyz12.ctypes.data,
+                                           xyz8.ctypes.data, xyz4.ctypes.data, rgba.ctypes.data), "pcr_las_upload")
+
+    def las_unload(self):
+        self._chk(self.lib.pcr_las_unload(self.h), "pcr_las_unload")
+
+    @property
+    def las_batches_loaded(self) -> int:
+        return int(self.lib.pcr_las_batches_loaded(self.h))
+
+    @property
+    def las_algorithmic_bytes(self) -> int:
+        return int(self.lib.pcr_las_algorithmic_bytes(self.h))
+
+    def render_las(self, p: RenderParams):
+        self._chk(self.lib.pcr_render_las(self.h, C.byref(p)), "pcr_render_las")
+
+    def resolve_las(self, p: RenderParams):
+        self._chk(self.lib.pcr_resolve_las(self.h, C.byref(p)), "pcr_resolve_las")
+
     def set_image_size(self, w: int, h: int):
         self._chk(self.lib.pcr_set_image_size(self.h, w, h), "pcr_set_image_size")
         self.width, self.height = w, h
@@ -515,4 +595,88 @@ class HuffmanHQS(_HuffmanMethod):
         ctx.render_hqs_depth(p)
         ctx.render_hqs_color(p)
         ctx.resolve_hqs(p)
+        self.last_params = p
+
+
+class ComputeLasData(Resource):
+    """modules/compute/ComputeLasLoader.{h,cpp}: a LAS file quantised batch by batch into three 10-10-10 levels.
+    The reference uploads raw LAS bytes and quantises in a compute shader (computeLasLoader.cs); here the host library
+    quantises (pcr_las_quantize) and the four arrays are uploaded."""
+
+    POINTS_PER_TASK = 100 * POINTS_PER_BATCH      # MAX_POINTS_PER_BATCH, Resources.h:10
+
+    def __init__(self):
+        super().__init__()
+        self.path = ""
+        self.numPoints = self.numPointsLoaded = self.numBatchesLoaded = 0
+        self._pts = None
+        self.las: Optional[LasInfo] = None
+
+    @staticmethod
+    def create(path: str) -> "ComputeLasData":                        # ComputeLasLoader.h:97-103
+        return ComputeLasData.from_points(*read_las(path), path=path)
+
+    @staticmethod
+    def from_points(x, y, z, color, las: LasInfo, path: str = "<memory>") -> "ComputeLasData":
+        d = ComputeLasData()
+        d.path, d.las = path, las
+        d._pts = tuple(np.ascontiguousarray(a, t) for a, t in ((x, np.int32), (y, np.int32), (z, np.int32), (color, np.uint32)))
+        d.numPoints = len(d._pts[0])
+        return d
+
+    def load(self, renderer: Renderer):                               # ComputeLasLoader.cpp:14-38
+        if self.state != Resource.UNLOADED:
+            return
+        self.state = Resource.LOADING
+        renderer.ctx.las_begin(self.numPoints)
+        self.numPointsLoaded = self.numBatchesLoaded = 0
+
+    def process(self, renderer: Renderer):                            # ComputeLasLoader.cpp:140-262
+        if self.state != Resource.LOADING:
+            return
+        a, b = self.numPointsLoaded, min(self.numPoints, self.numPointsLoaded + self.POINTS_PER_TASK)
+        q = las_quantize(*(v[a:b] for v in self._pts), self.las)
+        renderer.ctx.las_upload(self.numBatchesLoaded, *q)
+        self.numPointsLoaded = b
+        self.numBatchesLoaded = renderer.ctx.las_batches_loaded
+        if b == self.numPoints:
+            self.state = Resource.LOADED
+
+    def load_all(self, renderer: Renderer):
+        self.load(renderer)
+        while self.state == Resource.LOADING:
+            self.process(renderer)
+
+    def unload(self, renderer: Renderer):                             # ComputeLasLoader.cpp:114-131
+        self.numPointsLoaded = self.numBatchesLoaded = 0
+        renderer.ctx.las_unload()
+        self.state = Resource.UNLOADED
+
+
+class ComputeLoopLasCUDA(Method):
+    """modules/compute_loop_las_cuda/compute_loop_las_cuda.h:52-222: per-batch level of detail picks how many of the
+    three 10-bit levels a workgroup reads; {depth, point index} atomicMin; resolve looks the colour up by index."""
+    name = "loop_las_cuda"
+    description = "- Each thread renders X points.\n- Loads points from LAS file\n- encodes point coordinates in 10+10+10 bits"
+    group = "10-10-10 bit encoded"
+
+    def __init__(self, renderer: Renderer, las: ComputeLasData):
+        self.renderer, self.las = renderer, las
+
+    def update(self, renderer: Renderer):                             # empty in the reference (:92-93); resource switch as huffman_hqs.h:116-124
+        if Runtime.resource is not self.las:
+            if Runtime.resource is not None:
+                Runtime.resource.unload(renderer)
+            self.las.load(renderer)
+            Runtime.resource = self.las
+
+    def render(self, renderer: Renderer):                             # compute_loop_las_cuda.h:99-222
+        self.las.process(renderer)
+        if self.las.numPointsLoaded == 0:
+            return
+        p = renderer.render_params()
+        ctx = renderer.ctx
+        ctx.clear()
+        ctx.render_las(p)
+        ctx.resolve_las(p)
         self.last_params = p

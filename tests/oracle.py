@@ -8,7 +8,7 @@ import subprocess
 
 import numpy as np
 
-from pcrhpg24_amd._native import GpuBatch, RenderParams, RenderStats, fb_elems
+from pcrhpg24_amd._native import GpuBatch, RenderParams, RenderStats, XyzBatch, fb_elems
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
@@ -55,6 +55,12 @@ def lib() -> C.CDLL:
         L.pcr_oracle_resolve_hqs.restype = None
         L.pcr_oracle_decode_chain.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pcr_oracle_decode_chain.restype = None
+        L.pcr_oracle_las_level.argtypes = [C.POINTER(XyzBatch), C.POINTER(RenderParams)]
+        L.pcr_oracle_render_las.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RenderParams),
+                                            C.c_void_p, C.POINTER(RenderStats)]
+        L.pcr_oracle_render_las.restype = None
+        L.pcr_oracle_resolve_las.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pcr_oracle_resolve_las.restype = None
         _lib = L
     return _lib
 
@@ -160,4 +166,24 @@ def decode_chain(words, separate, dt_values, dt_cwlen, n: int) -> np.ndarray:
     lib().pcr_oracle_decode_chain(words.ctypes.data, len(words), separate.ctypes.data,
                                   np.ascontiguousarray(dt_values, np.int32).ctypes.data,
                                   np.ascontiguousarray(dt_cwlen, np.int32).ctypes.data, n, out.ctypes.data)
+    return out
+
+
+# ---- 10-10-10 path (modules/compute_loop_las_cuda) -------------------------------------------------
+def las_level(batch: XyzBatch, p: RenderParams) -> int:
+    return int(lib().pcr_oracle_las_level(C.byref(batch), C.byref(p)))
+
+
+def render_las(batches, xyz12, xyz8, xyz4, p: RenderParams, fb=None, num_batches=None):
+    fb = np.full(fb_elems(p.width, p.height), 0xFFFFFFFFFFFFFFFF, np.uint64) if fb is None else fb
+    st = RenderStats()
+    nb = len(batches) if num_batches is None else num_batches
+    lib().pcr_oracle_render_las(C.addressof(batches), nb, xyz12.ctypes.data, xyz8.ctypes.data, xyz4.ctypes.data,
+                                C.byref(p), fb.ctypes.data, C.byref(st))
+    return fb, st.as_dict()
+
+
+def resolve_las(p: RenderParams, fb: np.ndarray, rgba_points: np.ndarray) -> np.ndarray:
+    out = np.zeros(p.width * p.height, np.uint32)
+    lib().pcr_oracle_resolve_las(C.byref(p), fb.ctypes.data, rgba_points.ctypes.data, out.ctypes.data)
     return out

@@ -83,3 +83,27 @@ def test_render_cli_matches_oracle(tmp_path, method):
     assert np.array_equal(fb, ofb[:W * H])
     assert info["points_iterated"] == ost["points_iterated"] and info["covered_pixels"] == int((ofb[:W * H] != 2 ** 64 - 1).sum())
     assert (tmp_path / "o.ppm").stat().st_size > W * H * 3
+
+
+@pytest.mark.gpu
+def test_render_cli_loop_las_cuda_matches_oracle(tmp_path):
+    """pcr_render <file.las> --method loop_las_cuda: C++ ComputeLasData + ComputeLoopLasCUDA against the oracle."""
+    build.build_tools()
+    n = 5 * 65536 + 99
+    x, y, z, c = P.synth_points(n, scenes.SEED, 0, n)
+    r, g, b = (c & 255).astype(np.uint16), ((c >> 8) & 255).astype(np.uint16), ((c >> 16) & 255).astype(np.uint16)
+    write_las(tmp_path / "scene.las", x, y, z, r, g, b, offset=(0.0, 0.0, 0.0))
+    W, H = 640, 360
+    cam = ["-0.15", "-0.57", "1500", "500", "500", "40"]
+    res = subprocess.run([build.RENDER_BIN, str(tmp_path / "scene.las"), "--method", "loop_las_cuda", "--size", f"{W}x{H}",
+                          "--camera", *cam, "--dump-fb", str(tmp_path / "fb.u64")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["method"] == "loop_las_cuda" and info["batches"] == 6
+    px, py, pz, pc, las = P.read_las(str(tmp_path / "scene.las"))
+    q = P.las_quantize(px, py, pz, pc, las)
+    p = P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), W, H)
+    ofb, ost = oracle.render_las(*q[:4], p)
+    assert np.array_equal(np.fromfile(tmp_path / "fb.u64", np.uint64), ofb[:W * H])
+    assert info["points_iterated"] == ost["points_iterated"] == 5 * 65536
