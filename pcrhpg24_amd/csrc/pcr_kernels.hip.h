@@ -32,7 +32,8 @@ constexpr int ESC_POOL_WORDS = 6144;             // escape words of the whole ba
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
 constexpr int WIN_PIXELS     = 2560;             // u64 framebuffer window of the batch's rectangle -> 20 KiB
 constexpr int WIN_PIXELS_HQS = 1024;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 20 KiB
-constexpr uint32_t TE_LEN = 0xFFu, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u;   // packed table entry: len in byte 0, flags, value in bits 31:10
+// packed table entry: byte 0 = len, bit 31 = escape or wide (value not in the entry), bits 30:10 = value + TE_BIAS
+constexpr uint32_t TE_LEN = 0xFFu, TE_SLOW = 0x80000000u, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u, TE_BIAS = 1u << 20;
 constexpr int TE_VALUE_SHIFT = 10;
 
 // Device-side view of the loaded stream (own layout; the reference keeps nine flat CuBuffers,
@@ -251,9 +252,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const uint32_t l4 = reinterpret_cast<const uint32_t *>(a.s.table_lens + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
         auto pack = [](int32_t value, uint32_t lbyte) -> uint32_t {
             const int len = (int)(int8_t)lbyte;                             // render.cu:393 narrows to char
-            const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE : 0u);
+            const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE | TE_SLOW : 0u);
             if (len <= 0) return f;                                         // escapes never use the table value
-            return ((int32_t)((uint32_t)value << TE_VALUE_SHIFT) >> TE_VALUE_SHIFT) == value ? (((uint32_t)value << TE_VALUE_SHIFT) | f) : (f | TE_WIDE);
+            const uint32_t biased = (uint32_t)value + TE_BIAS;              // fits 21 bits <=> -2^20 <= value < 2^20
+            return biased < (2u * TE_BIAS) ? ((biased << TE_VALUE_SHIFT) | f) : (f | TE_WIDE | TE_SLOW);
         };
         uint4 e;
         e.x = pack(v.x, l4 & 0xFF); e.y = pack(v.y, (l4 >> 8) & 0xFF);
@@ -417,7 +419,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     __syncthreads();        // table, ring, escapes and window are visible
 
-    for (int seg = 0; seg < npr; seg += 16) {
+#ifdef PCR_EXP_PROLOGUE_ONLY   /* experiment only: cost of the per-batch set-up and the window merge (results are wrong) */
+    const int npr_run = a.p.reserved == 12345 ? npr : 0;
+#else
+    const int npr_run = npr;
+#endif
+    for (int seg = 0; seg < npr_run; seg += 16) {
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
       if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, seg - 1);
@@ -426,10 +433,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
           pal = bc1_palette(cnext);                     // once per 16 points instead of once per surviving point
           cnext = cblocks[min((seg >> 4) + 1, 3)];
       }
-      const int seg_end = min(seg + 16, npr);
+      const int seg_end = min(seg + 16, npr_run);
 #pragma unroll 1
       for (int i = seg; i < seg_end; ++i) {                                 // :428
-        int32_t dec[3];
+        uint32_t dec[3];
         {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {                                   // :430
@@ -437,8 +444,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 // :431-433 (== ((L|R) & mask) >> 20), i.e. the byte offset of its table entry
                 const uint32_t toff = (uint32_t)(bits >> sft) & 0x3FFCu;
                 const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff);   // :435-436
-                int32_t val = (int32_t)e >> TE_VALUE_SHIFT;
-                if (e & (TE_ESCAPE | TE_WIDE)) {
+                uint32_t biased = e >> TE_VALUE_SHIFT;                      // value + TE_BIAS; the bias leaves with the delta add below
+                if ((int32_t)e < 0) {                                       // escape or wide
+                    int32_t val;
                     if (e & TE_ESCAPE) {                                    // :438
                         if (sp < esc_lds) {
                             val = s_esc[sp];
@@ -452,6 +460,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                         val = tvalues[toff >> 2];
                         asm volatile("; wide table value from global memory %0" : "+v"(val));
                     }
+                    biased = (uint32_t)val + TE_BIAS;
                 }
                 sft -= e & TE_LEN;                                          // :439
                 const bool need = sft <= 18u;                               // :442 (cur_bits <= 0)
@@ -474,10 +483,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                dec[j] = val;
+                dec[j] = biased;
+#ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
+                {
+                    uint32_t pad = tid;
+#pragma unroll
+                    for (int k = 0; k < PCR_EXP_PAD_VALU; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
+                }
+#endif
             }
         }
-        px += dec[0]; py += dec[1]; pz += dec[2];                           // :454-456, :463
+        px = (int32_t)((uint32_t)px + dec[0] - TE_BIAS);                    // :454-456, :463
+        py = (int32_t)((uint32_t)py + dec[1] - TE_BIAS);
+        pz = (int32_t)((uint32_t)pz + dec[2] - TE_BIAS);
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
         continue;
@@ -542,7 +560,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
       }
     }
-    if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr - 1);
+    if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr_run - 1);
     if (MODE == MODE_HQS_COLOR) flush_run();
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave

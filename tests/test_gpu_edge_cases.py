@@ -52,11 +52,13 @@ def las_for(lo, hi, scale=0.001):
     return las
 
 
-def test_wide_table_values(ctx):
-    """Frequent symbols that do not fit the 26-bit packed LDS entry (+-2^30 deltas with short codes)."""
+@pytest.mark.parametrize("hop_bits", [30, 20])
+def test_wide_table_values(ctx, hop_bits):
+    """Frequent symbols that do not fit the packed LDS entry (+-2^30 deltas with short codes), and deltas straddling
+    the entry's value range (+-2^20 +- 2)."""
     rng = np.random.default_rng(21)
     n = 65536 * 2
-    hop = np.where(np.arange(n) % 2 == 0, 0, 1 << 30).astype(np.int64)
+    hop = np.where(np.arange(n) % 2 == 0, 0, 1 << hop_bits).astype(np.int64)
     x = (hop + rng.integers(0, 3, n)).astype(np.int32)
     y = rng.integers(0, 2000, n).astype(np.int32)
     z = rng.integers(0, 50, n).astype(np.int32)
@@ -65,7 +67,12 @@ def test_wide_table_values(ctx):
     of = oracle.OracleFile(image.view())
     tv = np.ctypeslib.as_array(__import__("ctypes").cast(of.s.dt_values, __import__("ctypes").POINTER(__import__("ctypes").c_int32)), (4096,))
     tl = np.ctypeslib.as_array(__import__("ctypes").cast(of.s.dt_cwlen, __import__("ctypes").POINTER(__import__("ctypes").c_int32)), (4096,))
-    assert (np.abs(tv[tl > 0].astype(np.int64)) >= 1 << 25).any(), "the stream must contain in-table values wider than 26 bits"
+    in_table = tv[tl > 0].astype(np.int64)
+    if hop_bits == 30:
+        assert (np.abs(in_table) >= 1 << 25).any(), "the stream must contain in-table values far outside the packed entry"
+    else:
+        for v in ((1 << 20) - 1, 1 << 20, -(1 << 20), -(1 << 20) - 1):
+            assert (in_table == v).any(), f"the stream must contain the in-table value {v}"
     ctx.set_image_size(320, 200)
     load(ctx, image)
     p = scenes.with_flags(P.camera_orbit(0.2, -0.8, 3.0e6, (5.0e5, 1.0, 0.0), 320, 200), lod_percent=100, cull=0)
