@@ -49,12 +49,21 @@ typedef struct pcr_encode_stats {
 const char *pcr_host_last_error(void);
 void pcr_host_free(void *p);
 
+/* Encoder flags. PCR_ENCODE_MORTON_SORT is the reference CLI's <sort> argument. PCR_ENCODE_PAD_TAILS is not in the
+ * reference: it queues a zero word for each refill the decoder performs after a chain's last real word, which removes
+ * the tail artefact of the reference's interleave (1-2 refills per chain for words that do not
+ * exist desynchronise the other lanes). Files written with it decode exactly, with the reference's kernels too; the
+ * default (flag clear) reproduces the reference's stream byte for byte, quirk included. */
+#define PCR_ENCODE_MORTON_SORT 1
+#define PCR_ENCODE_PAD_TAILS   2
+
 /* Encode n points (int32 LAS coordinates + 0x00BBGGRR colours) into a complete .huffman file image.
  * Points are processed in chunks of chunk_points (<=0: default); each chunk is padded, optionally
- * Morton-sorted, cut into batches and encoded, exactly like `preprocess in.las out.huffman <sort>`.
- * *out_bytes is malloc'ed; release with pcr_host_free. nthreads <= 0: hardware concurrency. */
+ * Morton-sorted, cut into batches and encoded, exactly like `preprocess in.las out.huffman <sort>`
+ * (flags = sort ? PCR_ENCODE_MORTON_SORT : 0). *out_bytes is malloc'ed; release with pcr_host_free.
+ * nthreads <= 0: hardware concurrency. */
 int pcr_encode_points(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color,
-                      int64_t n, const pcr_las_info *las, int morton_sort, int64_t chunk_points,
+                      int64_t n, const pcr_las_info *las, int flags, int64_t chunk_points,
                       int nthreads, void **out_bytes, size_t *out_len, pcr_encode_stats *stats);
 
 /* Deterministic synthetic scene: a heightfield surface over a square tile with LAS scale

@@ -191,6 +191,7 @@ int table_from_codes(const int32_t *syms, const Code *codes, size_t k, int32_t *
 
 // huffman.h:242-300: MSB-first packing, escape list, per-word completion index
 struct PackedChain {
+    int total_bits = 0;
     std::vector<uint32_t> words;
     std::vector<int32_t> separate;
     std::vector<int32_t> num_cw;
@@ -214,6 +215,7 @@ void pack_chain(const int32_t *symbols, int n, Lookup &&lookup, PackedChain &out
             acc <<= 32; fill -= 32;
         }
     }
+    out.total_bits = (int)out.words.size() * 32 + fill;
     if (fill > 0) {
         out.words.push_back((uint32_t)(acc >> 32));
         out.num_cw.push_back(n);
@@ -233,7 +235,7 @@ void put(std::vector<uint8_t> &buf, const void *p, size_t n)
 
 // x,y,z,color: 65536 points of this batch in final order. Appends one batch record to `rec`.
 int encode_batch(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color,
-                 int32_t point_offset, const pcr_las_info &las, std::vector<uint8_t> &rec, BatchStats &st)
+                 int32_t point_offset, const pcr_las_info &las, bool pad_tails, std::vector<uint8_t> &rec, BatchStats &st)
 {
     const int NT = PCR_WORKGROUP_SIZE, PPT = PCR_POINTS_PER_THREAD, N = PCR_POINTS_PER_BATCH;
     std::vector<int32_t> deltas((size_t)N * 3);
@@ -305,13 +307,21 @@ int encode_batch(const int32_t *x, const int32_t *y, const int32_t *z, const uin
             slots.push_back(Slot{-1, l, 0});
             slots.push_back(Slot{0, l, 1});
             for (int i = 2; i < nw; ++i) slots.push_back(Slot{pc[l].num_cw[i - 2], l, i});   // :558-563
+            if (pad_tails) {
+                // PCR_ENCODE_PAD_TAILS (not in the reference): the decoder refills every time a word runs dry, also
+                // for the last one or two words of a chain, for which the reference queues nothing. Queue
+                // a zero word for each of those refills so every lane's fetch order stays the one the decoder follows.
+                const int bits_total = pc[l].total_bits;
+                const int full = bits_total % 32 == 0 ? nw : nw - 1;          // words that run dry
+                for (int i = std::max(nw, 2); i < full + 2; ++i) slots.push_back(Slot{pc[l].num_cw[i - 2], l, i});
+            }
         }
         std::sort(slots.begin(), slots.end(), [](const Slot &a, const Slot &b) {               // :564
             if (a.time != b.time) return a.time < b.time;
             if (a.lane != b.lane) return a.lane < b.lane;
             return a.word < b.word;
         });
-        for (const Slot &s : slots) encoding.push_back(pc[s.lane].words[s.word]);
+        for (const Slot &s : slots) encoding.push_back(s.word < (int)pc[s.lane].words.size() ? pc[s.lane].words[s.word] : 0u);
         cluster_sizes[cl] = (int32_t)encoding.size();                       // inclusive prefix, :584-586
     }
     st.enc_words = (int64_t)encoding.size();
@@ -359,8 +369,9 @@ struct ChunkOut {
 };
 
 int encode_chunk(std::vector<int32_t> &x, std::vector<int32_t> &y, std::vector<int32_t> &z,
-                 std::vector<uint32_t> &c, const pcr_las_info &las, bool sort, ChunkOut &out)
+                 std::vector<uint32_t> &c, const pcr_las_info &las, int flags, ChunkOut &out)
 {
+    const bool sort = (flags & PCR_ENCODE_MORTON_SORT) != 0, pad_tails = (flags & PCR_ENCODE_PAD_TAILS) != 0;
     if (x.empty()) return fail("empty chunk");
     size_t n = x.size();
     size_t extra = (n % PCR_POINTS_PER_BATCH) ? PCR_POINTS_PER_BATCH - (n % PCR_POINTS_PER_BATCH) : 0;
@@ -391,7 +402,7 @@ int encode_chunk(std::vector<int32_t> &x, std::vector<int32_t> &y, std::vector<i
     for (size_t b = 0; b * PCR_POINTS_PER_BATCH < n; ++b) {
         size_t o = b * PCR_POINTS_PER_BATCH, before = out.bytes.size();
         BatchStats st;
-        if (encode_batch(&x[o], &y[o], &z[o], &c[o], (int32_t)o, las, out.bytes, st)) return -1;
+        if (encode_batch(&x[o], &y[o], &z[o], &c[o], (int32_t)o, las, pad_tails, out.bytes, st)) return -1;
         out.batch_sizes.push_back((int64_t)(out.bytes.size() - before));
         out.enc_words += st.enc_words; out.sep_words += st.sep_words; out.escaped += st.escaped;
     }
@@ -583,7 +594,7 @@ void pcr_morton_key(uint32_t x, uint32_t y, uint32_t z, uint32_t *hi, uint64_t *
 void pcr_bc1_encode_block(const uint32_t *colors16, uint8_t *out8) { bc1_encode(colors16, out8); }
 
 int pcr_encode_points(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color,
-                      int64_t n, const pcr_las_info *las, int morton_sort, int64_t chunk_points,
+                      int64_t n, const pcr_las_info *las, int flags, int64_t chunk_points,
                       int nthreads, void **out_bytes, size_t *out_len, pcr_encode_stats *stats)
 {
     if (!x || !y || !z || !color || !las || !out_bytes || !out_len) return fail("null argument");
@@ -595,7 +606,7 @@ int pcr_encode_points(const int32_t *x, const int32_t *y, const int32_t *z, cons
         int64_t a = c * chunk_points, b = std::min(n, a + chunk_points);
         std::vector<int32_t> cx(x + a, x + b), cy(y + a, y + b), cz(z + a, z + b);
         std::vector<uint32_t> cc(color + a, color + b);
-        return encode_chunk(cx, cy, cz, cc, *las, morton_sort != 0, chunks[(size_t)c]);
+        return encode_chunk(cx, cy, cz, cc, *las, flags, chunks[(size_t)c]);
     });
     if (rc) return rc;
     return assemble(chunks, n, out_bytes, out_len, stats);
@@ -644,7 +655,7 @@ int pcr_synth_encode(int64_t total_points, uint64_t seed, int64_t first, int64_t
         size_t m = (size_t)(b - a);
         std::vector<int32_t> cx(m), cy(m), cz(m); std::vector<uint32_t> cc(m);
         for (size_t i = 0; i < m; ++i) sc.point(a + (int64_t)i, cx[i], cy[i], cz[i], cc[i]);
-        return encode_chunk(cx, cy, cz, cc, las, true, chunks[(size_t)c]);
+        return encode_chunk(cx, cy, cz, cc, las, PCR_ENCODE_MORTON_SORT, chunks[(size_t)c]);
     });
     if (rc) return rc;
     return assemble(chunks, count, out_bytes, out_len, stats);

@@ -424,6 +424,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #else
     const int npr_run = npr;
 #endif
+    uint32_t toff_ahead = (uint32_t)(bits >> sft) & 0x3FFCu;
+    uint32_t e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
     for (int seg = 0; seg < npr_run; seg += 16) {
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
@@ -440,10 +442,17 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {                                   // :430
-                // bits is {cur, nxt}; sft = cur_bits + 18, so (bits >> sft) & 0x3FFC is 4 x the 12-bit window of
-                // :431-433 (== ((L|R) & mask) >> 20), i.e. the byte offset of its table entry
-                const uint32_t toff = (uint32_t)(bits >> sft) & 0x3FFCu;
-                const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff);   // :435-436
+                // `e` is the table entry of this symbol, fetched one step ahead. bits is {cur, nxt}; sft = cur_bits + 18,
+                // so (bits >> sft) & 0x3FFC is 4 x the 12-bit window of :431-433 (== ((L|R) & mask) >> 20), i.e. the
+                // byte offset of a table entry.
+                const uint32_t e = e_ahead, toff = toff_ahead;              // :435-436
+                sft -= e & TE_LEN;                                          // :439
+                // Entry of the NEXT symbol, requested before this step's refill: when the refill is due (sft <= 18)
+                // the next window lies wholly in `nxt`, which is bits [sft+2, sft+13] of the buffer as it is now, so
+                // the same expression serves both cases and the table read overlaps the ring read below instead of
+                // waiting for it (one LDS round trip per symbol on the critical path instead of two).
+                toff_ahead = (uint32_t)(bits >> sft) & 0x3FFCu;
+                e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
                 uint32_t biased = e >> TE_VALUE_SHIFT;                      // value + TE_BIAS; the bias leaves with the delta add below
                 if ((int32_t)e < 0) {                                       // escape or wide
                     int32_t val;
@@ -462,7 +471,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     }
                     biased = (uint32_t)val + TE_BIAS;
                 }
-                sft -= e & TE_LEN;                                          // :439
                 const bool need = sft <= 18u;                               // :442 (cur_bits <= 0)
                 const uint64_t m = __ballot(need);                          // :443
                 const uint32_t mh = (uint32_t)(m >> half_shift);

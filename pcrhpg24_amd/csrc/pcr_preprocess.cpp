@@ -13,10 +13,14 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) { std::fprintf(stderr, "usage: pcr_preprocess <in.las> <out.huffman> <sort 0|1> [threads]\n"); return 2; }   // preprocess.cpp:1169-1180
+    if (argc < 4) { std::fprintf(stderr, "usage: pcr_preprocess <in.las> <out.huffman> <sort 0|1> [threads] [--pad-tails]\n"); return 2; }   // preprocess.cpp:1169-1180
     const std::string in = argv[1], out = argv[2];
-    const int sort = std::atoi(argv[3]);
-    const int threads = argc > 4 ? std::atoi(argv[4]) : 0;
+    int flags = std::atoi(argv[3]) ? PCR_ENCODE_MORTON_SORT : 0;
+    int threads = 0;
+    for (int i = 4; i < argc; ++i) {
+        if (std::string(argv[i]) == "--pad-tails") flags |= PCR_ENCODE_PAD_TAILS;   // not in the reference, see pcr_encode.h
+        else threads = std::atoi(argv[i]);
+    }
     pcr_host::LasPoints pts;
     std::string err;
     if (!pcr_host::read_las(in, pts, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
@@ -25,7 +29,7 @@ int main(int argc, char **argv)
     const pcr_las_info &las = pts.las;
     const int64_t numPoints = pts.numPoints;
     void *bytes = nullptr; size_t len = 0; pcr_encode_stats st;
-    if (pcr_encode_points(x.data(), y.data(), z.data(), c.data(), numPoints, &las, sort, 0, threads, &bytes, &len, &st)) {
+    if (pcr_encode_points(x.data(), y.data(), z.data(), c.data(), numPoints, &las, flags, 0, threads, &bytes, &len, &st)) {
         std::fprintf(stderr, "encode failed: %s\n", pcr_host_last_error());
         return 1;
     }

@@ -59,6 +59,10 @@ def test_preprocess_cli_equals_library_encoder(tmp_path):
     assert (g0.scale_x, g0.offset_y) == (0.001, 20.0)
     assert abs(g0.las_min_x - (x.min() * 0.001 + 10.0)) < 1e-3
     assert subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "nope.las"), str(out), "1"], stderr=subprocess.PIPE).returncode != 0
+    fixed = tmp_path / "fixed.huffman"
+    assert subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "in.las"), str(fixed), "1", "2", "--pad-tails"], stdout=subprocess.PIPE).returncode == 0
+    image2, _ = P.encode_points(x, y, z, color, las, morton_sort=True, nthreads=2, pad_tails=True)
+    assert fixed.read_bytes() == bytes(image2.view()) and fixed.read_bytes() != out.read_bytes()
 
 
 @pytest.mark.gpu

@@ -175,3 +175,18 @@ def test_sharded_contexts_merge_to_the_single_context_result(ctx):
         assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
     finally:
         shard.close()
+
+
+def test_pad_tails_stream(ctx):
+    """A stream written with PCR_ENCODE_PAD_TAILS (zero words queued for the refills past each chain's end) goes through
+    the same kernels; all 64 points of every chain are drawn from exact coordinates (checked on the CPU side in
+    tests/test_oracle_format.py), and the framebuffer equals the oracle's."""
+    x, y, z, c = P.synth_points(150_000, scenes.SEED, 0, 150_000)
+    image, st = P.encode_points(x, y, z, c, P.synth_las_info(150_000), morton_sort=True, nthreads=2, pad_tails=True)
+    of = oracle.OracleFile(image.view())
+    ctx.set_image_size(640, 360)
+    load(ctx, image)
+    for cam in ("overview", "closeup"):
+        p = scenes.with_flags(scenes.cameras(640, 360)[cam], lod_percent=100, cull=0)
+        stt = check_all(ctx, of, p)
+        assert stt["points_iterated"] == of.num_batches * 65536

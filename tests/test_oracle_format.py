@@ -88,6 +88,36 @@ def test_decode_reproduces_source_except_reference_tail_artefact(total):
     assert bad_total < 0.02 * of.num_batches * 65536
 
 
+@pytest.mark.parametrize("case", ["mostly_padding", "surface", "escape_heavy"])
+def test_pad_tails_variant_decodes_every_point_exactly(case):
+    """PCR_ENCODE_PAD_TAILS (pcr_encode.h; SURVEY 8f-1 'fixed variant'): with a zero word queued for every refill past a
+    chain's last real word, the lane-accurate decode reproduces ALL source points; the default stream does not."""
+    if case == "mostly_padding":           # low-entropy chains: the reference artefact starts 32-64 symbols early
+        x, y, z, c = P.synth_points(10_000, scenes.SEED, 0, 10_000)
+        las = P.synth_las_info(10_000)
+    elif case == "surface":
+        x, y, z, c = P.synth_points(200_000, scenes.SEED, 0, 200_000)
+        las = P.synth_las_info(200_000)
+    else:
+        x, y, z, c, las = scenes.random_points(131072, seed=9)
+    fixed, st_fixed = P.encode_points(x, y, z, c, las, morton_sort=False, nthreads=2, pad_tails=True)
+    plain, st_plain = P.encode_points(x, y, z, c, las, morton_sort=False, nthreads=2)
+    of, op = oracle.OracleFile(fixed.view()), oracle.OracleFile(plain.view())
+    n = of.num_batches * 65536
+    pad = n - len(x)
+    src = np.stack([np.concatenate([v, np.full(pad, v[-1])]) for v in (x, y, z)], 1)
+    wrong_plain = 0
+    for b in range(of.num_batches):
+        assert np.array_equal(of.decode_batch(b).reshape(65536, 3), src[b * 65536:(b + 1) * 65536]), f"batch {b}"
+        wrong_plain += int((op.decode_batch(b).reshape(65536, 3) != src[b * 65536:(b + 1) * 65536]).any(1).sum())
+    if case != "escape_heavy":            # (high-entropy chains end so late that the misfires fall after the last symbol)
+        assert wrong_plain > 0                                          # the quirk the flag removes
+    # only zero words were added: 1-2 per chain, same escapes, same tables
+    extra = (st_fixed["encoded_bytes"] - st_plain["encoded_bytes"]) // 4
+    assert of.num_batches * 1024 <= extra <= of.num_batches * 2048
+    assert st_fixed["separate_bytes"] == st_plain["separate_bytes"] and st_fixed["escaped_symbols"] == st_plain["escaped_symbols"]
+
+
 def test_lod_truncation_is_a_prefix_of_the_full_decode():
     image, _ = scenes.synth_stream(200_000)
     of = oracle.OracleFile(image.view())
