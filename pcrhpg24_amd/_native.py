@@ -77,7 +77,7 @@ HIP_SYMBOLS = [
     "pcr_use_external_buffers", "pcr_merge_min", "pcr_merge_sum", "pcr_flip_sign", "pcr_timing_begin",
     "pcr_timing_end", "pcr_stream_algorithmic_bytes",
     "pcr_las_begin", "pcr_las_upload", "pcr_las_unload", "pcr_las_batches_loaded", "pcr_render_las", "pcr_resolve_las",
-    "pcr_las_algorithmic_bytes",
+    "pcr_las_algorithmic_bytes", "pcr_gpu_encode_points", "pcr_gpu_encode_free",
 ]
 
 HOST_SYMBOLS = [
@@ -124,6 +124,10 @@ def hip_lib() -> C.CDLL:
             getattr(lib, n).argtypes = [C.c_void_p, C.POINTER(RenderParams)]
         for n in ("pcr_render_las", "pcr_resolve_las"):
             getattr(lib, n).argtypes = [C.c_void_p, C.POINTER(RenderParams)]
+        lib.pcr_gpu_encode_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.POINTER(LasInfo),
+                                              C.c_int, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(EncodeStats)]
+        lib.pcr_gpu_encode_free.argtypes = [C.c_void_p]
+        lib.pcr_gpu_encode_free.restype = None
         lib.pcr_las_begin.argtypes = [C.c_void_p, c_i64]
         lib.pcr_las_upload.argtypes = [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pcr_las_unload.argtypes = [C.c_void_p]

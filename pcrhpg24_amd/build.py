@@ -1,7 +1,7 @@
 """In-tree builds of the native libraries (no JIT cache, no pip): the .so files land next to this
 file so they travel to the GPU box with the repository snapshot.
 
-    libpcr_hip.so   hipcc --offload-arch=gfx950   csrc/pcr_api.hip (+ pcr_kernels.hip.h)   the product hot path
+    libpcr_hip.so   hipcc --offload-arch=gfx950   csrc/pcr_api.hip (+ pcr_kernels.hip.h, pcr_gpu_encoder.hip.h)   hot path + GPU encoder
     libpcr_host.so  g++                           csrc/pcr_encoder.cpp                     CPU encoder / generator / camera
 """
 from __future__ import annotations
@@ -46,18 +46,19 @@ def _hipcc() -> str:
 
 
 def build_hip(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, "pcr_api.hip"), os.path.join(CSRC, "pcr_kernels.hip.h"),
-            os.path.join(INCLUDE, "pcr_hip.h"), os.path.join(INCLUDE, "pcr_types.h")]
+    srcs = [os.path.join(CSRC, "pcr_api.hip"), os.path.join(CSRC, "pcr_kernels.hip.h"), os.path.join(CSRC, "pcr_gpu_encoder.hip.h"),
+            os.path.join(CSRC, "pcr_codec_common.h"), os.path.join(INCLUDE, "pcr_hip.h"), os.path.join(INCLUDE, "pcr_types.h"),
+            os.path.join(INCLUDE, "pcr_encode.h"), os.path.join(INCLUDE, "pcr_gpu_encode.h")]
     if force or _stale(HIP_LIB, srcs):
         _run([_hipcc(), *HIP_FLAGS, "-I", INCLUDE, "-I", CSRC, srcs[0], "-o", HIP_LIB])
     return HIP_LIB
 
 
 def build_host(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, "pcr_encoder.cpp"), os.path.join(INCLUDE, "pcr_encode.h"),
+    srcs = [os.path.join(CSRC, "pcr_encoder.cpp"), os.path.join(CSRC, "pcr_codec_common.h"), os.path.join(INCLUDE, "pcr_encode.h"),
             os.path.join(INCLUDE, "pcr_types.h")]
     if force or _stale(HOST_LIB, srcs):
-        _run(["g++", *HOST_FLAGS, "-I", INCLUDE, srcs[0], "-o", HOST_LIB, "-lpthread"])
+        _run(["g++", *HOST_FLAGS, "-I", INCLUDE, "-I", CSRC, srcs[0], "-o", HOST_LIB, "-lpthread"])
     return HOST_LIB
 
 
@@ -75,10 +76,10 @@ def build_tools(force: bool = False) -> None:
     if force or _stale(RENDER_BIN, rsrc):
         _run([_hipcc(), "-O2", "-std=c++17", "-I", INCLUDE, "-I", CSRC, rsrc[0], "-o", RENDER_BIN,
               "-L", PKG_DIR, "-lpcr_hip", "-lpcr_host", "-lpthread", "-Wl,-rpath,$ORIGIN"])
-    psrc = [os.path.join(CSRC, "pcr_preprocess.cpp"), os.path.join(CSRC, "pcr_las_reader.hpp"), HOST_LIB]
+    psrc = [os.path.join(CSRC, "pcr_preprocess.cpp"), os.path.join(CSRC, "pcr_las_reader.hpp"), HOST_LIB, HIP_LIB]
     if force or _stale(PREPROCESS_BIN, psrc):
         _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", CSRC, psrc[0], "-o", PREPROCESS_BIN,
-              "-L", PKG_DIR, "-lpcr_host", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+              "-L", PKG_DIR, "-lpcr_host", "-lpcr_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
 
 
 def build_all(force: bool = False) -> None:

@@ -718,3 +718,5 @@ int pcr_timing_end(pcr_ctx *c, float *ms)
 }
 
 } // extern "C"
+
+#include "pcr_gpu_encoder.hip.h"   // pcr_gpu_encode_points (include/pcr_gpu_encode.h)

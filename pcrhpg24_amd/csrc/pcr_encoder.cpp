@@ -7,6 +7,7 @@
 //     tie-break, so streams are reproducible on any libstdc++ (the reference's depend on hash order)
 //   * chunks are generated / sorted / encoded by a thread pool; batches inside a chunk are independent
 #include "pcr_encode.h"
+#include "pcr_codec_common.h"
 
 #include <algorithm>
 #include <atomic>
@@ -24,87 +25,7 @@ namespace {
 thread_local std::string g_err;
 int fail(const char *msg) { g_err = msg; return -1; }
 
-// ---------------------------------------------------------------------------------------------
-// Morton key (src/mymorton.h:12-37)
-// ---------------------------------------------------------------------------------------------
-struct MortonKey {
-    uint32_t hi; uint64_t lo;
-    bool operator<(const MortonKey &o) const { return hi != o.hi ? hi < o.hi : lo < o.lo; }
-    bool operator==(const MortonKey &o) const { return hi == o.hi && lo == o.lo; }
-};
-
-inline uint64_t spread3_21(uint32_t v) // bits 0..20 of v to positions 3i
-{
-    uint64_t x = v & 0x1FFFFFu;
-    x = (x | x << 32) & 0x1F00000000FFFFull;
-    x = (x | x << 16) & 0x1F0000FF0000FFull;
-    x = (x | x << 8)  & 0x100F00F00F00F00Full;
-    x = (x | x << 4)  & 0x10C30C30C30C30C3ull;
-    x = (x | x << 2)  & 0x1249249249249249ull;
-    return x;
-}
-
-inline MortonKey morton_key(uint32_t X, uint32_t Y, uint32_t Z)
-{
-    MortonKey k;
-    k.lo = spread3_21(X) | (spread3_21(Y) << 1) | (spread3_21(Z) << 2);     // mymorton.h:16-20
-    k.lo |= (uint64_t)((X >> 21) & 1u) << 63;                                // :23
-    // The reference accumulates these in 64-bit arithmetic and stores them into a uint32_t (mymorton.h:10,30-34):
-    // bit 31 of X would land on bit 32 and is dropped by that truncation. Reproduced, not fixed.
-    uint64_t hi = ((Y >> 21) & 1u) | (((Z >> 21) & 1u) << 1);                // :26-27
-    for (int i = 22; i < 32; ++i) {                                          // :30-34
-        hi |= (uint64_t)((X >> i) & 1u) << (3 * (i - 21) + 2);
-        hi |= (uint64_t)((Y >> i) & 1u) << (3 * (i - 21) + 0);
-        hi |= (uint64_t)((Z >> i) & 1u) << (3 * (i - 21) + 1);
-    }
-    k.hi = (uint32_t)hi;
-    return k;
-}
-
-inline uint32_t shift_coord(int32_t v) { return (uint32_t)((int64_t)v - (int64_t)INT32_MIN); } // mymorton.h:47-49
-
-// ---------------------------------------------------------------------------------------------
-// BC1 (4-colour mode only; decoder = modules/huffman_mem_iter_cuda/render.cu:23-65)
-// ---------------------------------------------------------------------------------------------
-inline void expand565(uint32_t c, int &r, int &g, int &b)
-{
-    int cr = (c >> 11) & 31, cg = (c >> 5) & 63, cb = c & 31;
-    r = (cr << 3) | (cr >> 2); g = (cg << 2) | (cg >> 4); b = (cb << 3) | (cb >> 2);
-}
-
-void bc1_encode(const uint32_t *px, uint8_t *out)
-{
-    int mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
-    for (int i = 0; i < 16; ++i)
-        for (int c = 0; c < 3; ++c) {
-            int v = (px[i] >> (8 * c)) & 255;
-            mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v);
-        }
-    auto to565 = [](const int *c) {
-        int r = (c[0] * 31 + 127) / 255, g = (c[1] * 63 + 127) / 255, b = (c[2] * 31 + 127) / 255;
-        return (uint32_t)((r << 11) | (g << 5) | b);
-    };
-    uint32_t c0 = to565(mx), c1 = to565(mn);
-    if (c0 < c1) std::swap(c0, c1);
-    int pal[4][3];
-    expand565(c0, pal[0][0], pal[0][1], pal[0][2]);
-    expand565(c1, pal[1][0], pal[1][1], pal[1][2]);
-    for (int c = 0; c < 3; ++c) {
-        pal[2][c] = (pal[0][c] * 2 + pal[1][c]) / 3;
-        pal[3][c] = (pal[0][c] + pal[1][c] * 2) / 3;
-    }
-    out[0] = c0 & 255; out[1] = c0 >> 8; out[2] = c1 & 255; out[3] = c1 >> 8;
-    out[4] = out[5] = out[6] = out[7] = 0;
-    for (int i = 0; i < 16; ++i) {
-        int best = 0, bestd = 1 << 30;
-        for (int k = 0; k < 4; ++k) {
-            int d = 0;
-            for (int c = 0; c < 3; ++c) { int e = (int)((px[i] >> (8 * c)) & 255) - pal[k][c]; d += e * e; }
-            if (d < bestd) { bestd = d; best = k; }
-        }
-        out[4 + i / 4] |= (uint8_t)(best << (2 * (i % 4)));
-    }
-}
+using pcr_codec::MortonKey; using pcr_codec::morton_key; using pcr_codec::shift_coord; using pcr_codec::bc1_encode;   // pcr_codec_common.h
 
 // ---------------------------------------------------------------------------------------------
 // Clipped Huffman code (include/huffman.h:58-69, 94-113, 180-240)

@@ -8,17 +8,19 @@
 #include <string>
 #include <vector>
 
-#include "pcr_encode.h"
+#include "pcr_gpu_encode.h"
 #include "pcr_las_reader.hpp"
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) { std::fprintf(stderr, "usage: pcr_preprocess <in.las> <out.huffman> <sort 0|1> [threads] [--pad-tails]\n"); return 2; }   // preprocess.cpp:1169-1180
+    if (argc < 4) { std::fprintf(stderr, "usage: pcr_preprocess <in.las> <out.huffman> <sort 0|1> [threads] [--pad-tails] [--gpu]\n"); return 2; }   // preprocess.cpp:1169-1180
     const std::string in = argv[1], out = argv[2];
     int flags = std::atoi(argv[3]) ? PCR_ENCODE_MORTON_SORT : 0;
     int threads = 0;
+    bool gpu = false;
     for (int i = 4; i < argc; ++i) {
         if (std::string(argv[i]) == "--pad-tails") flags |= PCR_ENCODE_PAD_TAILS;   // not in the reference, see pcr_encode.h
+        else if (std::string(argv[i]) == "--gpu") gpu = true;                       // pcr_gpu_encode_points: same bytes, encoded on the MI355X
         else threads = std::atoi(argv[i]);
     }
     pcr_host::LasPoints pts;
@@ -29,7 +31,16 @@ int main(int argc, char **argv)
     const pcr_las_info &las = pts.las;
     const int64_t numPoints = pts.numPoints;
     void *bytes = nullptr; size_t len = 0; pcr_encode_stats st;
-    if (pcr_encode_points(x.data(), y.data(), z.data(), c.data(), numPoints, &las, flags, 0, threads, &bytes, &len, &st)) {
+    if (gpu) {
+        pcr_ctx *ctx = nullptr;
+        if (pcr_create(0, &ctx)) { std::fprintf(stderr, "pcr_create: %s\n", pcr_last_error(nullptr)); return 1; }
+        if (pcr_gpu_encode_points(ctx, x.data(), y.data(), z.data(), c.data(), numPoints, &las, flags, 0, &bytes, &len, &st)) {
+            std::fprintf(stderr, "GPU encode failed: %s\n", pcr_last_error(ctx));
+            pcr_destroy(ctx);
+            return 1;
+        }
+        pcr_destroy(ctx);
+    } else if (pcr_encode_points(x.data(), y.data(), z.data(), c.data(), numPoints, &las, flags, 0, threads, &bytes, &len, &st)) {
         std::fprintf(stderr, "encode failed: %s\n", pcr_host_last_error());
         return 1;
     }

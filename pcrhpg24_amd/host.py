@@ -305,6 +305,18 @@ class Context:
         return int(self.lib.pcr_stream_algorithmic_bytes(self.h))
 
     # method side
+    # -- GPU encoder (include/pcr_gpu_encode.h) ---------------------------------------------------------
+    def gpu_encode_points(self, x, y, z, color, las: LasInfo, morton_sort: bool = True, chunk_points: int = 0,
+                          pad_tails: bool = False) -> tuple[NativeBytes, dict]:
+        """The encoder of `encode_points`, run on the GPU; same file image byte for byte."""
+        x = np.ascontiguousarray(x, np.int32); y = np.ascontiguousarray(y, np.int32); z = np.ascontiguousarray(z, np.int32)
+        color = np.ascontiguousarray(color, np.uint32)
+        out, ln, st = C.c_void_p(), C.c_size_t(), EncodeStats()
+        self._chk(self.lib.pcr_gpu_encode_points(self.h, x.ctypes.data, y.ctypes.data, z.ctypes.data, color.ctypes.data, len(x),
+                                                 C.byref(las), int(bool(morton_sort)) | (2 if pad_tails else 0), chunk_points,
+                                                 C.byref(out), C.byref(ln), C.byref(st)), "pcr_gpu_encode_points")
+        return NativeBytes(out.value, ln.value), st.as_dict()
+
     # -- 10-10-10 resource / method ----------------------------------------------------------------
     def las_begin(self, num_points: int):
         self._chk(self.lib.pcr_las_begin(self.h, num_points), "pcr_las_begin")

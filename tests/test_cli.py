@@ -111,3 +111,19 @@ def test_render_cli_loop_las_cuda_matches_oracle(tmp_path):
     ofb, ost = oracle.render_las(*q[:4], p)
     assert np.array_equal(np.fromfile(tmp_path / "fb.u64", np.uint64), ofb[:W * H])
     assert info["points_iterated"] == ost["points_iterated"] == 5 * 65536
+
+
+@pytest.mark.gpu
+def test_preprocess_cli_gpu_equals_cpu(tmp_path):
+    """pcr_preprocess --gpu (pcr_gpu_encode_points) writes the same file as the CPU path."""
+    build.build_tools()
+    n = 150_000
+    x, y, z, c = P.synth_points(n, scenes.SEED, 0, n)
+    r, g, b = (c & 255).astype(np.uint16), ((c >> 8) & 255).astype(np.uint16), ((c >> 16) & 255).astype(np.uint16)
+    write_las(tmp_path / "in.las", x, y, z, r, g, b)
+    for extra in ([], ["--pad-tails"]):
+        a, bb = tmp_path / "cpu.huffman", tmp_path / "gpu.huffman"
+        assert subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "in.las"), str(a), "1", "4", *extra], stdout=subprocess.PIPE).returncode == 0
+        res = subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "in.las"), str(bb), "1", "--gpu", *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert res.returncode == 0, res.stderr
+        assert a.read_bytes() == bb.read_bytes()
