@@ -1,0 +1,104 @@
+"""BASELINE.json configs[1] at full size on the GPU: 1e8 synthetic points, 1526 batches, 1920x1080, LOD 100 %, culling
+off. Direct parity against the oracle (its multi-threaded basic pass takes well under a second at this size) plus the
+size-independent properties of the path: shard-and-merge equals the whole, rendering twice changes nothing, the depth
+halves of the basic and the HQS depth pass agree, the GPU encoder reproduces the stream."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import pcrhpg24_amd as P
+from tests import oracle, scenes
+
+pytestmark = pytest.mark.gpu
+
+N = 100_000_000
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def big():
+    image, st = P.synth_encode(N, scenes.SEED, nthreads=16)
+    assert st["num_batches"] == 1526 and st["num_points"] == 100_007_936
+    return image, P.HuffmanFile(image), oracle.OracleFile(image.view())
+
+
+@pytest.fixture(scope="module")
+def whole(big):
+    image, hf, of = big
+    ctx = P.Context(0)
+    ctx.set_image_size(W, H)
+    ctx.stream_begin(hf.header(), 0)
+    for b0 in range(0, hf.numBatches, 100):
+        ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
+    yield ctx
+    ctx.close()
+
+
+def params(cam="overview"):
+    return scenes.with_flags(scenes.cameras(W, H)[cam], lod_percent=100, cull=0)
+
+
+def test_basic_pass_equals_oracle_at_full_size(big, whole):
+    _, _, of = big
+    p = params()
+    whole.clear(); whole.render_basic(p); whole.resolve_basic(p)
+    fb = whole.read_framebuffer(full=True)
+    ofb, ost = of.render_basic(p, nthreads=16)
+    assert whole.stats() == ost and ost["points_iterated"] == 100_007_936
+    assert np.array_equal(fb, ofb)
+    assert np.array_equal(whole.read_rgba(), oracle.resolve_basic(p, ofb))
+    # rendering the same stream again into the same framebuffer changes nothing (min is idempotent)
+    whole.render_basic(p)
+    assert np.array_equal(whole.read_framebuffer(full=True), fb)
+
+
+def test_hqs_passes_equal_oracle_at_full_size(big, whole):
+    _, _, of = big
+    p = params()
+    whole.clear(); whole.render_hqs_depth(p)
+    dfb = whole.read_framebuffer(full=True)
+    ofb, ost = of.render_hqs_depth(p)
+    assert whole.stats() == ost and np.array_equal(dfb, ofb)
+    whole.render_hqs_color(p); whole.resolve_hqs(p)
+    rg, ba = whole.read_accum(full=True)
+    org, oba, _ = of.render_hqs_color(p, ofb)
+    assert np.array_equal(rg, org) and np.array_equal(ba, oba)
+    assert np.array_equal(whole.read_rgba(), oracle.resolve_hqs(p, ofb, org, oba))
+    # the depth halves of the two methods are the same min over the same points
+    whole.clear(); whole.render_basic(p)
+    bfb = whole.read_framebuffer(full=True)
+    assert np.array_equal(bfb >> np.uint64(32), dfb >> np.uint64(32))
+
+
+def test_two_shards_merge_to_the_whole(big, whole):
+    """contiguous batch ranges on separate contexts, one min-merge; the second shard's head words ride along."""
+    _, hf, _ = big
+    p = params("closeup")
+    whole.clear(); whole.render_basic(p)
+    ref = whole.read_framebuffer(full=True)
+    cut = 763
+    parts = []
+    for first, count in ((0, cut), (cut, hf.numBatches - cut)):
+        c = P.Context(0)
+        c.set_image_size(W, H)
+        c.stream_begin(hf.header(first, count), first)
+        for b0 in range(0, count, 100):
+            c.upload_batches(b0, [hf.blob(first + b) for b in range(b0, min(b0 + 100, count))])
+        if first + count < hf.numBatches:
+            c.upload_tail(*hf.head_words(first + count))
+        c.clear(); c.render_basic(p)
+        parts.append(c)
+    parts[1].synchronize()
+    parts[0].merge_min(parts[1].device_framebuffer())
+    merged = parts[0].read_framebuffer(full=True)
+    for c in parts:
+        c.close()
+    assert np.array_equal(merged, ref)
+
+
+def test_gpu_encoder_reproduces_the_stream(big, whole):
+    image, _, _ = big
+    x, y, z, c = P.synth_points(N, scenes.SEED, 0, N)
+    gpu, st = whole.gpu_encode_points(x, y, z, c, P.synth_las_info(N, scenes.SEED), morton_sort=True)
+    assert hashlib.sha256(gpu.view()).digest() == hashlib.sha256(image.view()).digest()
