@@ -30,8 +30,12 @@ constexpr int CHUNK_WORDS    = 64;               // stream staging granule per c
 constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                                   -> 16 KiB
 constexpr int ESC_POOL_WORDS = 6144;             // escape words of the whole batch, pooled        -> 24 KiB
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
-constexpr int WIN_PIXELS     = 2560;             // u64 framebuffer window of the batch's rectangle -> 20 KiB
-constexpr int WIN_PIXELS_HQS = 1024;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 20 KiB
+constexpr int WIN_PIXELS     = 4608;             // u64 framebuffer window of the batch's rectangle -> 36 KiB
+constexpr int WIN_PIXELS_HQS = 1843;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 36 KiB
+// Lane-major copy of the word stream (k_transcode): row r holds the r-th word each of the batch's 1024 chains consumes.
+// A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
+constexpr int LW_ROWS        = 80;
+constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
 // packed table entry: byte 0 = len, bit 31 = escape or wide (value not in the entry), bits 30:10 = value + TE_BIAS
 constexpr uint32_t TE_LEN = 0xFFu, TE_SLOW = 0x80000000u, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u, TE_BIAS = 1u << 20;
 constexpr int TE_VALUE_SHIFT = 10;
@@ -49,6 +53,7 @@ struct StreamView {
     const int8_t   *table_lens;       // [nB*4096]
     const int32_t  *cluster_sizes;    // [nB*32]
     const uint8_t  *colors;           // [nB*32768]
+    const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
@@ -227,6 +232,73 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
     return (sel & 2u) ? hi : lo;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_transcode: the reference's lockstep decode (render.cu:404-451), run ONCE per loaded batch instead of every frame.
+//
+// The stream format interleaves the words of 32 chains in the order a 32-lane warp requests them, so finding "my next
+// word" costs a ballot, a prefix count and a shared read per symbol — and the reference's tail quirk makes
+// the word a lane receives depend on what the other 31 lanes did. This kernel performs exactly that walk (lengths only:
+// no values, no escapes, no points) and writes down, per chain, the sequence of words it received: row r of
+// lane_words holds the r-th word of each of the 1024 chains. k_render then decodes every chain from its own word
+// sequence — same bits, same symbols, garbage tails included — without any cross-lane step. A decode truncated by the
+// level of detail consumes a prefix of the same sequence (the walk is causal), so one transcode serves every frame.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, int first_batch)
+{
+    const uint32_t b = (uint32_t)first_batch + blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    __shared__ __align__(16) uint8_t s_len[PCR_HUFFMAN_TABLE_SIZE];
+    __shared__ __align__(16) uint32_t s_ring[PCR_CLUSTERS_PER_BATCH * RING_WORDS];
+    {
+        const uint32_t l4 = reinterpret_cast<const uint32_t *>(s.table_lens + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+        auto alen = [](uint32_t lbyte) -> uint32_t { return (uint32_t)abs((int)(int8_t)lbyte); };   // render.cu:393, :439
+        reinterpret_cast<uint32_t *>(s_len)[tid] = alen(l4 & 0xFF) | (alen((l4 >> 8) & 0xFF) << 8) | (alen((l4 >> 16) & 0xFF) << 16) | (alen(l4 >> 24) << 24);
+    }
+    const pcr_gpu_batch *gb = s.batches + b;
+    const int64_t enc_off = gb->encoding_batch_offset;      // :404
+    const uint32_t *enc = s.encoded + enc_off;
+    const uint32_t enc_last = (uint32_t)min((int64_t)0x7FFFFFF0, s.encoded_words + (PCR_GUARD_WORDS - 2) - enc_off);
+    auto enc_load = [&](uint32_t i) -> uint32_t { return enc[min(i, enc_last)]; };
+    auto enc_load2 = [&](uint32_t i) -> uint2 { uint2 v; __builtin_memcpy(&v, enc + min(i, enc_last), 8); return v; };
+    const uint32_t cluster = tid >> 5, lane32 = tid & 31u, half_shift = tid & 32u, lanes_below = (1u << lane32) - 1u;
+    const uint32_t cbase = cluster ? (uint32_t)s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;   // :407-410
+    uint32_t *ring = s_ring + cluster * RING_WORDS;
+    uint32_t *out = lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE + tid;
+    uint32_t row = 2;
+    uint64_t bits = ((uint64_t)enc_load(cbase + lane32) << 32) | enc_load(cbase + 32 + lane32);   // :416-417
+    out[0] = (uint32_t)(bits >> 32);
+    out[PCR_WORKGROUP_SIZE] = (uint32_t)bits;
+    reinterpret_cast<uint2 *>(ring + CHUNK_WORDS)[lane32] = enc_load2(cbase + CHUNK_WORDS + lane32 * 2);
+    reinterpret_cast<uint2 *>(ring)[lane32] = enc_load2(cbase + 2 * CHUNK_WORDS + lane32 * 2);
+    uint2 stage = enc_load2(cbase + 3 * CHUNK_WORDS + lane32 * 2);
+    uint32_t ep = 64, next_cross = 2 * CHUNK_WORDS;         // already_read (:418)
+    uint32_t sft = 32 + 20;                                 // cur_bits (:419) + 20: (bits >> sft) & 0xFFF is the key of :431-433
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < PCR_POINTS_PER_THREAD * 3; ++k) {   // :428-430
+        sft -= s_len[(uint32_t)(bits >> sft) & 0xFFFu];     // :435-439
+        const bool need = sft <= 20u;                       // :442 (cur_bits <= 0)
+        const uint64_t m = __ballot(need);                  // :443
+        const uint32_t mh = (uint32_t)(m >> half_shift);
+        if (need) {                                         // :444-449
+            const uint32_t w = ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
+            out[(size_t)row * PCR_WORKGROUP_SIZE] = w;
+            ++row;
+            bits = (bits << 32) | w;
+            sft += 32;
+        }
+        ep += __popc(mh);                                   // :450
+        if (ep >= next_cross) {                             // same ring protocol as described in k_render's history
+            reinterpret_cast<uint2 *>(ring + ((next_cross + CHUNK_WORDS) & (RING_WORDS - 1)))[lane32] = stage;
+            stage = enc_load2(cbase + next_cross + 2 * CHUNK_WORDS + lane32 * 2);
+            next_cross += CHUNK_WORDS;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -241,7 +313,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t tid = threadIdx.x;
 
     __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
-    __shared__ __align__(16) uint32_t s_ring[PCR_CLUSTERS_PER_BATCH * RING_WORDS];
     __shared__ __align__(16) int32_t s_esc[ESC_POOL_WORDS];
     __shared__ __align__(16) unsigned long long s_win[WIN_PIXELS];
 
@@ -264,27 +335,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     }
 
     const pcr_gpu_batch *gb = a.s.batches + b;
-    const int64_t enc_off = gb->encoding_batch_offset;      // :404
     const int64_t sep_off = gb->separate_batch_offset;      // :405
-    const uint32_t *enc = a.s.encoded + enc_off;            // batch-relative bases (uniform)
-    const int32_t *sep = a.s.separate + sep_off;
-    // Reads past the logical end of a stream (zero pad included) are defined as 0. The allocations carry
+    const int32_t *sep = a.s.separate + sep_off;            // batch-relative base (uniform)
+    // Reads past the logical end of the escape stream (zero pad included) are defined as 0. The allocation carries
     // PCR_GUARD_WORDS extra zero words that nothing ever writes, so clamping the index to the guard is enough:
     // branch-free loads keep every global load of the loop on one control-flow path (no conservative waits).
-    const uint32_t enc_last = (uint32_t)min((int64_t)0x7FFFFFF0, a.s.encoded_words + (PCR_GUARD_WORDS - 2) - enc_off);
     const uint32_t sep_last = (uint32_t)min((int64_t)0x7FFFFFF0, a.s.separate_words + (PCR_GUARD_WORDS - 2) - sep_off);
-    auto enc_load = [&](uint32_t i) -> uint32_t { return enc[min(i, enc_last)]; };
     auto sep_load = [&](uint32_t i) -> int32_t { return sep[min(i, sep_last)]; };
-    auto enc_load2 = [&](uint32_t i) -> uint2 {             // two consecutive stream words, 4-byte aligned
-        uint2 v;
-        __builtin_memcpy(&v, enc + min(i, enc_last), 8);
-        return v;
-    };
-
-    const uint32_t cluster = tid >> 5;                      // 32-lane cluster of the stream format
-    const uint32_t lane32 = tid & 31u;
-    const uint32_t half_shift = tid & 32u;                  // which half of the wave64 ballot is mine
-    const uint32_t lanes_below = (1u << lane32) - 1u;       // (CUDA's mask << (32 - tid), without the shift-by-32)
 
     // ---- escape words of the batch -> LDS (all of them, or none) --------------------------------------------
     const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
@@ -329,15 +386,15 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         }
     }
 
-    // ---- word stream of my cluster: words 0..63 straight to registers, chunks 1,2 to the ring, chunk 3 staged
-    const uint32_t cbase = cluster ? (uint32_t)a.s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;   // :407-410
-    uint32_t *ring = s_ring + cluster * RING_WORDS;
-    uint64_t bits = ((uint64_t)enc_load(cbase + lane32) << 32) | enc_load(cbase + 32 + lane32);   // {CurHuffman, NextHuffman} :416-417
-    reinterpret_cast<uint2 *>(ring + CHUNK_WORDS)[lane32] = enc_load2(cbase + CHUNK_WORDS + lane32 * 2);
-    reinterpret_cast<uint2 *>(ring)[lane32] = enc_load2(cbase + 2 * CHUNK_WORDS + lane32 * 2);
-    uint2 stage = enc_load2(cbase + 3 * CHUNK_WORDS + lane32 * 2);
-    uint32_t ep = 64;                                       // already_read (:418): next stream word of the cluster
-    uint32_t next_cross = 2 * CHUNK_WORDS;                  // ep value at which the ring's older chunk is dead
+    // ---- my chain's own word sequence (k_transcode): {CurHuffman, NextHuffman} (:416-417), the next two words in
+    // registers, and the two after those requested one point ahead of their first possible use
+    const char *lwb = reinterpret_cast<const char *>(a.s.lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE);   // uniform
+    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + byte_off); };
+    uint32_t lwo = tid * 4;                                 // byte offset of my column; bits 1:0 count this point's refills
+    uint64_t bits = ((uint64_t)lw_load(lwo) << 32) | lw_load(lwo + LW_ROW_BYTES);
+    uint32_t ahead = lw_load(lwo + 2 * LW_ROW_BYTES), ahead1 = lw_load(lwo + 3 * LW_ROW_BYTES);
+    uint32_t far0 = lw_load(lwo + 4 * LW_ROW_BYTES), far1 = lw_load(lwo + 5 * LW_ROW_BYTES);
+    lwo += 4 * LW_ROW_BYTES;                                // row of far0
     uint32_t sft = 32 + 18;                                 // cur_bits (:419) + 18, see the decode step
 
     const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + tid) * 3;   // :421-424
@@ -365,10 +422,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // framebuffer word `old` was fetched one iteration earlier, from the LDS window (widx) or from global memory.
     // A stale `old` only makes the filter less selective: framebuffer words never increase during a pass.
     // colour pass: run of contributions to one pixel held in registers
+    // (two 16-bit sums per register: a chain adds at most 64 * 255 per channel)
     uint32_t run_pix = NO_PIXEL, run_widx = NO_PIXEL;
-    unsigned long long run_rg = 0, run_ba = 0;
+    uint32_t run_rg16 = 0, run_bc16 = 0;                    // r << 16 | g,  b << 16 | count
     auto flush_run = [&]() {
         if (run_pix == NO_PIXEL) return;
+        const unsigned long long run_rg = ((unsigned long long)(run_rg16 >> 16) << 32) | (run_rg16 & 0xFFFFu);
+        const unsigned long long run_ba = ((unsigned long long)(run_bc16 >> 16) << 32) | (run_bc16 & 0xFFFFu);
         if (run_widx != NO_PIXEL) {
             // per-batch partial sums in LDS (a batch adds at most 65 536 * 255 < 2^32 per 32-bit half)
             __hip_atomic_fetch_add(&s_rg[run_widx], run_rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -384,16 +444,16 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             const float old_depth = __uint_as_float((uint32_t)(old >> 32));
             if ((double)pw <= (double)old_depth * 1.01) {                   // hqs render.cu:296
                 const uint32_t rgba = bc1_color(pal, (uint32_t)point & 15u);
-                const uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, bl = (rgba >> 16) & 255u;
-                const unsigned long long vrg = (r << 32) | g, vba = (bl << 32) | 1u;
+                const uint32_t vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);   // r << 16 | g  (rgba = 0x00BBGGRR)
+                const uint32_t vbc = (rgba & 0x00FF0000u) | 1u;                        // b << 16 | 1
                 // Consecutive points of a chain are Morton neighbours and mostly land in the same pixel: their
                 // contributions are summed in registers and written once per run (sums commute, so the totals
                 // are unchanged; a chain adds at most 64 * 255 per 32-bit half).
                 if (pix == run_pix) {
-                    run_rg += vrg; run_ba += vba;
+                    run_rg16 += vrg; run_bc16 += vbc;
                 } else {
                     flush_run();
-                    run_pix = pix; run_widx = widx; run_rg = vrg; run_ba = vba;
+                    run_pix = pix; run_widx = widx; run_rg16 = vrg; run_bc16 = vbc;
                 }
             }
             return;
@@ -410,6 +470,18 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         if (widx != NO_PIXEL) __hip_atomic_fetch_min(&s_win[widx], (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else                  atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);   // :300
     };
+
+    // Word queue: a point uses c <= 2 of {ahead, ahead1}; they are topped up from the two words requested a point ago
+    // and the next two are requested (memory latency gets a whole point, and no load sits inside the symbol steps).
+#define PCR_TOP_UP_WORD_QUEUE()                                                   \
+    do {                                                                          \
+        const uint32_t c_ = lwo & 3u;                                             \
+        ahead1 = c_ == 1u ? far0 : c_ == 2u ? far1 : ahead1;                      \
+        ahead = c_ == 2u ? far0 : ahead;                                          \
+        lwo += c_ * (LW_ROW_BYTES - 1u);                                          \
+        far0 = lw_load(lwo);                                                      \
+        far1 = lw_load(lwo + LW_ROW_BYTES);                                       \
+    } while (0)
 
     uint32_t pend_pix = NO_PIXEL, pend_widx = NO_PIXEL, pend_depth = 0;
     uint64_t pend_old = 0;
@@ -471,26 +543,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     }
                     biased = (uint32_t)val + TE_BIAS;
                 }
-                const bool need = sft <= 18u;                               // :442 (cur_bits <= 0)
-                const uint64_t m = __ballot(need);                          // :443
-                const uint32_t mh = (uint32_t)(m >> half_shift);
-                if (need) {                                                 // :444-449
-                    bits = (bits << 32) | ring[(ep + __popc(mh & lanes_below)) & (RING_WORDS - 1)];
+                if (sft <= 18u) {                                           // :442-449 (cur_bits <= 0): Cur = Next, Next = my next word
+                    bits = (bits << 32) | ahead;                            // at most two refills per point (3 x 12 bits)
+                    ahead = ahead1;
                     sft += 32;
+                    lwo += 1;
                 }
-                ep += __popc(mh);                                           // :450
-                if (ep >= next_cross) {
-                    // My half of the wave has consumed the ring's older chunk (a step takes at most 32 words, so every
-                    // refill stays inside the two resident chunks): overwrite it with the staged chunk and fetch the
-                    // chunk after that. Wave-internal LDS traffic: DS operations of a wave execute in order, the
-                    // fences below only stop the compiler from reordering.
-                    reinterpret_cast<uint2 *>(ring + ((next_cross + CHUNK_WORDS) & (RING_WORDS - 1)))[lane32] = stage;
-                    stage = enc_load2(cbase + next_cross + 2 * CHUNK_WORDS + lane32 * 2);
-                    next_cross += CHUNK_WORDS;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 dec[j] = biased;
 #ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
                 {
@@ -504,6 +562,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         px = (int32_t)((uint32_t)px + dec[0] - TE_BIAS);                    // :454-456, :463
         py = (int32_t)((uint32_t)py + dec[1] - TE_BIAS);
         pz = (int32_t)((uint32_t)pz + dec[2] - TE_BIAS);
+        PCR_TOP_UP_WORD_QUEUE();
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
         continue;
