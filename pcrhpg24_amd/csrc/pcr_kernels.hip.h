@@ -36,6 +36,9 @@ constexpr int WIN_PIXELS_HQS = 1843;             // colour pass: {RG u64, BA u64
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
 constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
+// batch_flags: set when some chain of the batch can meet an in-table value outside the packed entry's range or read an
+// escape word outside k_render's LDS pool (k_transcode walks all 192 symbols of every chain, garbage tails included)
+constexpr uint32_t BF_GENERIC_SLOW_PATH = 1u;
 // packed table entry: byte 0 = len, bit 31 = escape or wide (value not in the entry), bits 30:10 = value + TE_BIAS
 constexpr uint32_t TE_LEN = 0xFFu, TE_SLOW = 0x80000000u, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u, TE_BIAS = 1u << 20;
 constexpr int TE_VALUE_SHIFT = 10;
@@ -54,6 +57,7 @@ struct StreamView {
     const int32_t  *cluster_sizes;    // [nB*32]
     const uint8_t  *colors;           // [nB*32768]
     const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
+    const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
@@ -242,17 +246,27 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
 // lane_words holds the r-th word of each of the 1024 chains. k_render then decodes every chain from its own word
 // sequence — same bits, same symbols, garbage tails included — without any cross-lane step. A decode truncated by the
 // level of detail consumes a prefix of the same sequence (the walk is causal), so one transcode serves every frame.
+// The walk also counts the escapes every chain reads, which tells whether k_render may take them from its LDS pool
+// without checking (batch_flags).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, int first_batch)
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags, int first_batch)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
     __shared__ __align__(16) uint8_t s_len[PCR_HUFFMAN_TABLE_SIZE];
     __shared__ __align__(16) uint32_t s_ring[PCR_CLUSTERS_PER_BATCH * RING_WORDS];
+    bool generic = false;
     {
         const uint32_t l4 = reinterpret_cast<const uint32_t *>(s.table_lens + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
-        auto alen = [](uint32_t lbyte) -> uint32_t { return (uint32_t)abs((int)(int8_t)lbyte); };   // render.cu:393, :439
-        reinterpret_cast<uint32_t *>(s_len)[tid] = alen(l4 & 0xFF) | (alen((l4 >> 8) & 0xFF) << 8) | (alen((l4 >> 16) & 0xFF) << 16) | (alen(l4 >> 24) << 24);
+        const int4 v = reinterpret_cast<const int4 *>(s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+        // byte: |len| (render.cu:393, :439), bit 7: escape (len <= 0, as k_render packs it)
+        auto entry = [&](uint32_t lbyte, int32_t value) -> uint32_t {
+            const int len = (int)(int8_t)lbyte;
+            if (len > 0 && (uint32_t)value + TE_BIAS >= 2u * TE_BIAS) generic = true;      // "wide" entry of k_render's table
+            return (uint32_t)abs(len) | (len <= 0 ? 0x80u : 0u);
+        };
+        reinterpret_cast<uint32_t *>(s_len)[tid] = entry(l4 & 0xFF, v.x) | (entry((l4 >> 8) & 0xFF, v.y) << 8) |
+                                                   (entry((l4 >> 16) & 0xFF, v.z) << 16) | (entry(l4 >> 24, v.w) << 24);
     }
     const pcr_gpu_batch *gb = s.batches + b;
     const int64_t enc_off = gb->encoding_batch_offset;      // :404
@@ -273,10 +287,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     uint2 stage = enc_load2(cbase + 3 * CHUNK_WORDS + lane32 * 2);
     uint32_t ep = 64, next_cross = 2 * CHUNK_WORDS;         // already_read (:418)
     uint32_t sft = 32 + 20;                                 // cur_bits (:419) + 20: (bits >> sft) & 0xFFF is the key of :431-433
+    uint32_t nesc = 0;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < PCR_POINTS_PER_THREAD * 3; ++k) {   // :428-430
-        sft -= s_len[(uint32_t)(bits >> sft) & 0xFFFu];     // :435-439
+        const uint32_t l = s_len[(uint32_t)(bits >> sft) & 0xFFFu];
+        sft -= l & 0x7Fu;                                   // :435-439
+        nesc += l >> 7;                                     // :438
         const bool need = sft <= 20u;                       // :442 (cur_bits <= 0)
         const uint64_t m = __ballot(need);                  // :443
         const uint32_t mh = (uint32_t)(m >> half_shift);
@@ -297,6 +314,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // may k_render read this batch's escapes from its LDS pool unchecked? (same pool rule as there)
+    const int32_t *ssz = s.separate_sizes + (size_t)b * 1024;
+    const uint32_t esc_total = (uint32_t)ssz[1023];
+    const uint32_t esc_lds = esc_total + ESC_SLACK <= (uint32_t)ESC_POOL_WORDS ? esc_total + ESC_SLACK : 0u;
+    const uint32_t sp0 = tid ? (uint32_t)ssz[tid - 1] : 0u;
+    if (nesc && sp0 + nesc > esc_lds) generic = true;
+    const int any = __syncthreads_or(generic ? 1 : 0);
+    if (tid == 0) batch_flags[b] = any ? BF_GENERIC_SLOW_PATH : 0u;
 }
 
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
@@ -310,6 +335,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     if (lod & LOD_CULLED) return;
     const int npr = (int)(lod & LOD_NPR_MASK);
     const bool use_double = (lod & LOD_DOUBLE) != 0;
+    const bool generic_slow = (a.s.batch_flags[b] & BF_GENERIC_SLOW_PATH) != 0;
     const uint32_t tid = threadIdx.x;
 
     __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
@@ -528,7 +554,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 uint32_t biased = e >> TE_VALUE_SHIFT;                      // value + TE_BIAS; the bias leaves with the delta add below
                 if ((int32_t)e < 0) {                                       // escape or wide
                     int32_t val;
-                    if (e & TE_ESCAPE) {                                    // :438
+                    if (!generic_slow) {                                    // (uniform) every such entry is an escape whose word is in the pool
+                        val = s_esc[sp];
+                        ++sp;
+                    } else if (e & TE_ESCAPE) {                             // :438
                         if (sp < esc_lds) {
                             val = s_esc[sp];
                         } else {
