@@ -412,16 +412,23 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         }
     }
 
-    // ---- my chain's own word sequence (k_transcode): {CurHuffman, NextHuffman} (:416-417), the next two words in
-    // registers, and the two after those requested one point ahead of their first possible use
+    // ---- my chain's own word sequence (k_transcode) ---------------------------------------------------------
+    // The chain's bit stream is the concatenation of its words. w0..w2 are three consecutive words, `spare` = 32 minus
+    // the number of bits of w0 already consumed (0..31); far0/far1 are the two words after w2, requested one point
+    // before they can be needed. Per point a 64-bit view `bits` of the next unconsumed bits is cut out once, the three
+    // symbols (<= 36 bits) and the look-ahead of the next point's first symbol (12 more) index into it, and the words
+    // that ran dry are retired afterwards: no refill test, load or wait inside the symbol steps.
+    // (Cur/Next of :416-419 are the first two words; the stand-in w0 = 0 is "fully consumed" from the start.)
     const char *lwb = reinterpret_cast<const char *>(a.s.lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE);   // uniform
     auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + byte_off); };
-    uint32_t lwo = tid * 4;                                 // byte offset of my column; bits 1:0 count this point's refills
-    uint64_t bits = ((uint64_t)lw_load(lwo) << 32) | lw_load(lwo + LW_ROW_BYTES);
-    uint32_t ahead = lw_load(lwo + 2 * LW_ROW_BYTES), ahead1 = lw_load(lwo + 3 * LW_ROW_BYTES);
-    uint32_t far0 = lw_load(lwo + 4 * LW_ROW_BYTES), far1 = lw_load(lwo + 5 * LW_ROW_BYTES);
-    lwo += 4 * LW_ROW_BYTES;                                // row of far0
-    uint32_t sft = 32 + 18;                                 // cur_bits (:419) + 18, see the decode step
+    uint32_t lwo = tid * 4;                                 // byte offset of my column in the row of far0
+    uint32_t w0 = 0, w1 = lw_load(lwo), w2 = lw_load(lwo + LW_ROW_BYTES);
+    uint32_t far0 = lw_load(lwo + 2 * LW_ROW_BYTES), far1 = lw_load(lwo + 3 * LW_ROW_BYTES);
+    lwo += 2 * LW_ROW_BYTES;
+    uint32_t spare = 0;
+    uint64_t bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
+    constexpr uint32_t SFT0 = 50;                           // (bits >> 50) & 0x3FFC = 4 x the top 12 bits of the view
+    uint32_t sft = SFT0;
 
     const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + tid) * 3;   // :421-424
     int32_t px = sv[0], py = sv[1], pz = sv[2];
@@ -497,16 +504,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         else                  atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);   // :300
     };
 
-    // Word queue: a point uses c <= 2 of {ahead, ahead1}; they are topped up from the two words requested a point ago
-    // and the next two are requested (memory latency gets a whole point, and no load sits inside the symbol steps).
-#define PCR_TOP_UP_WORD_QUEUE()                                                   \
-    do {                                                                          \
-        const uint32_t c_ = lwo & 3u;                                             \
-        ahead1 = c_ == 1u ? far0 : c_ == 2u ? far1 : ahead1;                      \
-        ahead = c_ == 2u ? far0 : ahead;                                          \
-        lwo += c_ * (LW_ROW_BYTES - 1u);                                          \
-        far0 = lw_load(lwo);                                                      \
-        far1 = lw_load(lwo + LW_ROW_BYTES);                                       \
+    // End of a point: SFT0 - sft bits were consumed. Retire the 0..2 words that ran dry, pull in far0/far1 (requested a
+    // whole point ago), request the next two, cut the next view. u = spare - consumed + 64 lies in [28, 95].
+#define PCR_ADVANCE_WORD_WINDOW()                                                          \
+    do {                                                                                   \
+        const uint32_t u_ = spare + sft + (64u - SFT0);                                    \
+        const uint32_t k_ = u_ >> 5;               /* 2: no word retired, 1: one, 0: two */ \
+        spare = u_ & 31u;                                                                  \
+        const uint32_t n0_ = k_ == 2u ? w0 : k_ == 1u ? w1 : w2;                           \
+        const uint32_t n1_ = k_ == 2u ? w1 : k_ == 1u ? w2 : far0;                         \
+        const uint32_t n2_ = k_ == 2u ? w2 : k_ == 1u ? far0 : far1;                       \
+        w0 = n0_; w1 = n1_; w2 = n2_;                                                      \
+        lwo += (2u - k_) * LW_ROW_BYTES;                                                   \
+        far0 = lw_load(lwo);                                                               \
+        far1 = lw_load(lwo + LW_ROW_BYTES);                                                \
+        bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare); \
+        sft = SFT0;                                                                        \
     } while (0)
 
     uint32_t pend_pix = NO_PIXEL, pend_widx = NO_PIXEL, pend_depth = 0;
@@ -540,15 +553,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {                                   // :430
-                // `e` is the table entry of this symbol, fetched one step ahead. bits is {cur, nxt}; sft = cur_bits + 18,
-                // so (bits >> sft) & 0x3FFC is 4 x the 12-bit window of :431-433 (== ((L|R) & mask) >> 20), i.e. the
-                // byte offset of a table entry.
+                // `e` is the table entry of this symbol, fetched one step ahead; (bits >> sft) & 0x3FFC is 4 x the 12-bit
+                // window of :431-433 (== ((L|R) & mask) >> 20) at the current position, i.e. the byte offset of an entry
                 const uint32_t e = e_ahead, toff = toff_ahead;              // :435-436
                 sft -= e & TE_LEN;                                          // :439
-                // Entry of the NEXT symbol, requested before this step's refill: when the refill is due (sft <= 18)
-                // the next window lies wholly in `nxt`, which is bits [sft+2, sft+13] of the buffer as it is now, so
-                // the same expression serves both cases and the table read overlaps the ring read below instead of
-                // waiting for it (one LDS round trip per symbol on the critical path instead of two).
                 toff_ahead = (uint32_t)(bits >> sft) & 0x3FFCu;
                 e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
                 uint32_t biased = e >> TE_VALUE_SHIFT;                      // value + TE_BIAS; the bias leaves with the delta add below
@@ -572,12 +580,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     }
                     biased = (uint32_t)val + TE_BIAS;
                 }
-                if (sft <= 18u) {                                           // :442-449 (cur_bits <= 0): Cur = Next, Next = my next word
-                    bits = (bits << 32) | ahead;                            // at most two refills per point (3 x 12 bits)
-                    ahead = ahead1;
-                    sft += 32;
-                    lwo += 1;
-                }
                 dec[j] = biased;
 #ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
                 {
@@ -591,7 +593,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         px = (int32_t)((uint32_t)px + dec[0] - TE_BIAS);                    // :454-456, :463
         py = (int32_t)((uint32_t)py + dec[1] - TE_BIAS);
         pz = (int32_t)((uint32_t)pz + dec[2] - TE_BIAS);
-        PCR_TOP_UP_WORD_QUEUE();
+        PCR_ADVANCE_WORD_WINDOW();
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
         continue;
