@@ -5,10 +5,12 @@
 //
 // Kernels
 //   k_lod_prepass   one thread per batch: frustum cull + LOD (render.cu:333-379) -> lod word per batch + stats
-//   k_render<MODE>  one 1024-thread workgroup per batch = 16 wave64 = 32 clusters of 32 chains; each lane
-//                   decodes its chain of <= 64 points from the cluster-interleaved stream with the batch's
-//                   decoder table in LDS, then projects and scatters every point (render.cu:383-540,
-//                   huffman_hqs/depth.cu, huffman_hqs/render.cu)
+//   k_transcode     once per loaded batch: the reference's lockstep walk over the cluster-interleaved stream
+//                   (render.cu:404-451), recording per chain the words it receives -> lane-major stream
+//   k_render<MODE>  every frame, one 1024-thread workgroup per batch, one chain per lane: decodes the chain of
+//                   <= 64 points from its own word sequence with the batch's decoder table in LDS, then projects
+//                   and scatters every point (render.cu:383-540, huffman_hqs/depth.cu, huffman_hqs/render.cu)
+//   k_las_*         the 10-10-10 method (modules/compute_loop_las_cuda)
 //   k_resolve_*     framebuffer -> RGBA8 (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
 //   k_merge_* / k_flip_sign  multi-GPU partial-framebuffer merges
 #pragma once
@@ -191,22 +193,20 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode + rasterize: one workgroup per batch, 16 wave64 = 32 stream clusters
+// decode + rasterize: one workgroup per batch, one chain per lane (lanes are independent after k_transcode)
 //
 // Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
-//   s_table  16 KiB  decoder table packed to one dword per key: value<<10 | wide<<9 | escape<<8 | len
-//                    (a table value that does not fit 22 bits is flagged `wide` and re-read from global memory)
-//   s_ring   16 KiB  per cluster a 128-word ring of its word stream, filled 64 words at a time by coalesced
-//                    8-byte-per-lane loads issued one chunk ahead and staged in registers, so the per-symbol
-//                    refill is an LDS read instead of a dependent global load
+//   s_table  16 KiB  decoder table packed to one dword per key: slow<<31 | (value + 2^20)<<10 | wide<<9 | escape<<8 | len
+//                    (an in-table value outside +-2^20 is flagged `wide` and re-read from global memory)
 //   s_esc    24 KiB  the escape ("separate") words of the batch, bulk-loaded coalesced up front (batches with
 //                    more than ESC_POOL_WORDS escapes read them from global memory instead)
-//   s_win    20 KiB  the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
+//   s_win    36 KiB  the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
 //                    and the atomicMin of every point that lands inside run on LDS (ds_read_b64 / ds_min_u64);
 //                    at the end the rectangle is merged into the global framebuffer with one row-coalesced
 //                    atomicMin per improved pixel. min is associative, so the result is the same u64 per pixel;
 //                    what changes is the number of global atomics: one per touched pixel and batch instead of
-//                    one per new per-pixel minimum (6.9 -> ~1.5 per covered pixel on the benchmark frame).
+//                    one per new per-pixel minimum.
+//   registers        three words of the chain's own sequence + two requested a point ahead (see the word window below)
 // Global loads left in the loop are consumed at least one iteration after they are issued.
 // ------------------------------------------------------------------------------------------------
 // BC1 block -> its four palette colours as 0x00BBGGRR (render.cu:31-62, always 4-colour mode)
