@@ -41,6 +41,7 @@ struct pcr_ctx {
     uint32_t *d_lod = nullptr;
     uint2 *d_win = nullptr;
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
+    uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
     uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
     int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words are final
     pcr_render_stats *d_stats = nullptr;
@@ -95,7 +96,7 @@ void free_stream_buffers(pcr_ctx *c)
 {
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
-    dfree(c->d_lane_words); dfree(c->d_batch_flags); c->transcoded = 0;
+    dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); c->transcoded = 0;
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
@@ -142,7 +143,7 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.s.batches = c->d_batches; a.s.start_values = c->d_start; a.s.encoded = c->d_encoded;
     a.s.separate = c->d_separate; a.s.separate_sizes = c->d_sep_sizes; a.s.table_values = c->d_table_values;
     a.s.table_lens = c->d_table_lens; a.s.cluster_sizes = c->d_cluster_sizes; a.s.colors = c->d_colors;
-    a.s.lane_words = c->d_lane_words; a.s.batch_flags = c->d_batch_flags;
+    a.s.lane_words = c->d_lane_words; a.s.batch_flags = c->d_batch_flags; a.s.packed_table = c->d_packed_table;
     a.s.encoded_words = c->enc_words; a.s.separate_words = c->sep_words;
     a.s.num_batches = c->batches_loaded; a.s.batch_index_base = c->batch_index_base;
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
@@ -163,7 +164,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
         // redone with them: its chains' tail over-reads reach into the words that follow it, which were
         // the zero pad until now. The very last batch stays provisional for the same reason until the stream is complete.
         const int64_t first = c->transcoded;
-        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(nB - first)), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a.s, c->d_lane_words, c->d_batch_flags, (int)first);
+        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(nB - first)), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a.s, c->d_lane_words, c->d_batch_flags, c->d_packed_table, (int)first);
         c->transcoded = nB == c->hdr.num_batches ? nB : nB - 1;
     }
     HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream));
@@ -269,7 +270,8 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096)) ||
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32)) ||
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB)) || (rc = dalloc_zero(c, c->d_win, nB)) ||
-        (rc = dalloc_zero(c, c->d_lane_words, nB * LW_ROWS * PCR_WORKGROUP_SIZE)) || (rc = dalloc_zero(c, c->d_batch_flags, nB))) {
+        (rc = dalloc_zero(c, c->d_lane_words, nB * LW_ROWS * PCR_WORKGROUP_SIZE)) || (rc = dalloc_zero(c, c->d_batch_flags, nB)) ||
+        (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE))) {
         free_stream_buffers(c);
         return rc;
     }
@@ -453,8 +455,8 @@ int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
 {
     if (!c || !c->stream_open) return 0;
     // every compressed byte once + per-batch side data (GPUBatch + start values + escape prefix + table
-    // as stored here: 16 KiB values + 4 KiB lengths) + cluster prefix
-    const int64_t per_batch = 160 + 12288 + 4096 + (16384 + 4096) + 128;
+    // as k_render reads it: 16 KiB of packed entries) + cluster prefix
+    const int64_t per_batch = 160 + 12288 + 4096 + 16384 + 128;
     return c->enc_ptr * 4 + c->sep_ptr * 4 + c->batches_loaded * per_batch;
 }
 

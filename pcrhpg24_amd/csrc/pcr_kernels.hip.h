@@ -60,6 +60,7 @@ struct StreamView {
     const uint8_t  *colors;           // [nB*32768]
     const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
+    const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
@@ -236,6 +237,16 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
     return (sel & 2u) ? hi : lo;
 }
 
+// One packed dword per table key (layout above): value and length of render.cu:435-439 in a single LDS read.
+__device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lbyte)
+{
+    const int len = (int)(int8_t)lbyte;                             // render.cu:393 narrows to char
+    const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE | TE_SLOW : 0u);
+    if (len <= 0) return f;                                         // escapes never use the table value
+    const uint32_t biased = (uint32_t)value + TE_BIAS;              // fits 21 bits <=> -2^20 <= value < 2^20
+    return biased < (2u * TE_BIAS) ? ((biased << TE_VALUE_SHIFT) | f) : (f | TE_WIDE | TE_SLOW);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_transcode: the reference's lockstep decode (render.cu:404-451), run ONCE per loaded batch instead of every frame.
 //
@@ -249,7 +260,8 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
 // The walk also counts the escapes every chain reads, which tells whether k_render may take them from its LDS pool
 // without checking (batch_flags).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags, int first_batch)
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
+                                                                  uint32_t *packed_table, int first_batch)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -267,6 +279,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         };
         reinterpret_cast<uint32_t *>(s_len)[tid] = entry(l4 & 0xFF, v.x) | (entry((l4 >> 8) & 0xFF, v.y) << 8) |
                                                    (entry((l4 >> 16) & 0xFF, v.z) << 16) | (entry(l4 >> 24, v.w) << 24);
+        // k_render's table, packed once here instead of by every frame's prologue
+        uint4 e;
+        e.x = pack_table_entry(v.x, l4 & 0xFF); e.y = pack_table_entry(v.y, (l4 >> 8) & 0xFF);
+        e.z = pack_table_entry(v.z, (l4 >> 16) & 0xFF); e.w = pack_table_entry(v.w, l4 >> 24);
+        reinterpret_cast<uint4 *>(packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid] = e;
     }
     const pcr_gpu_batch *gb = s.batches + b;
     const int64_t enc_off = gb->encoding_batch_offset;      // :404
@@ -342,23 +359,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     __shared__ __align__(16) int32_t s_esc[ESC_POOL_WORDS];
     __shared__ __align__(16) unsigned long long s_win[WIN_PIXELS];
 
-    // decoder table -> LDS (render.cu:383-395), four entries per thread
-    const int32_t *tvalues = a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE;
-    {
-        const int4 v = reinterpret_cast<const int4 *>(tvalues)[tid];
-        const uint32_t l4 = reinterpret_cast<const uint32_t *>(a.s.table_lens + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
-        auto pack = [](int32_t value, uint32_t lbyte) -> uint32_t {
-            const int len = (int)(int8_t)lbyte;                             // render.cu:393 narrows to char
-            const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE | TE_SLOW : 0u);
-            if (len <= 0) return f;                                         // escapes never use the table value
-            const uint32_t biased = (uint32_t)value + TE_BIAS;              // fits 21 bits <=> -2^20 <= value < 2^20
-            return biased < (2u * TE_BIAS) ? ((biased << TE_VALUE_SHIFT) | f) : (f | TE_WIDE | TE_SLOW);
-        };
-        uint4 e;
-        e.x = pack(v.x, l4 & 0xFF); e.y = pack(v.y, (l4 >> 8) & 0xFF);
-        e.z = pack(v.z, (l4 >> 16) & 0xFF); e.w = pack(v.w, l4 >> 24);
-        reinterpret_cast<uint4 *>(s_table)[tid] = e;
-    }
+    // decoder table -> LDS (render.cu:383-395), four entries per thread, already packed by k_transcode
+    const int32_t *tvalues = a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE;   // only for `wide` entries
+    reinterpret_cast<uint4 *>(s_table)[tid] = reinterpret_cast<const uint4 *>(a.s.packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
 
     const pcr_gpu_batch *gb = a.s.batches + b;
     const int64_t sep_off = gb->separate_batch_offset;      // :405
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         for (int k = 0; k < ESC_POOL_WORDS / PCR_WORKGROUP_SIZE; ++k) v[k] = sep_load(tid + k * PCR_WORKGROUP_SIZE);
 #pragma unroll
         for (int k = 0; k < ESC_POOL_WORDS / PCR_WORKGROUP_SIZE; ++k)
-            if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = v[k];
+            if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = (int32_t)((uint32_t)v[k] + TE_BIAS);   // stored biased, like table values
     }
     uint32_t sp = tid ? (uint32_t)ssz[tid - 1] : 0u;        // :411-413 (batch-relative)
 
@@ -563,11 +566,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 if ((int32_t)e < 0) {                                       // escape or wide
                     int32_t val;
                     if (!generic_slow) {                                    // (uniform) every such entry is an escape whose word is in the pool
-                        val = s_esc[sp];
+                        val = s_esc[sp] - (int32_t)TE_BIAS;                 // (folds with the + TE_BIAS below)
                         ++sp;
                     } else if (e & TE_ESCAPE) {                             // :438
                         if (sp < esc_lds) {
-                            val = s_esc[sp];
+                            val = s_esc[sp] - (int32_t)TE_BIAS;
                         } else {
                             // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
                             val = sep_load(sp);
