@@ -16,6 +16,8 @@
 
 using namespace pcr;
 
+constexpr int PCR_STATS_PARTIALS = 256;         // ceil(65535 batches / 256 prepass threads)
+
 struct pcr_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -44,7 +46,8 @@ struct pcr_ctx {
     uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
     uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
     int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words are final
-    pcr_render_stats *d_stats = nullptr;
+    pcr_render_stats *d_stats = nullptr;        // PCR_STATS_PARTIALS partial records, one per prepass workgroup
+    int stats_partials = 0;                     // how many the last render launch wrote
     // pinned staging arenas of the loader (double-buffered)
     uint8_t *arena[2] = {nullptr, nullptr};
     size_t arena_size[2] = {0, 0};
@@ -156,7 +159,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     int rc = check_params(c, p);
     if (rc) return rc;
     const int64_t nB = c->batches_loaded;            // "don't execute a workgroup until all points inside are loaded"
-    if (nB == 0) return PCR_OK;                      // huffman_hqs.h:137
+    if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
     a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
     if (c->transcoded < nB) {
@@ -167,8 +170,8 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
         hipLaunchKernelGGL(k_transcode, dim3((unsigned)(nB - first)), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a.s, c->d_lane_words, c->d_batch_flags, c->d_packed_table, (int)first);
         c->transcoded = nB == c->hdr.num_batches ? nB : nB - 1;
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream));
-    hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, c->stream, a);
+    c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
+    hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return PCR_OK;
@@ -201,12 +204,11 @@ int pcr_create(int device, pcr_ctx **out)
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&c->arena_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->arena_done[1], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&c->d_stats, sizeof(pcr_render_stats)) != hipSuccess) {
+        hipMalloc((void **)&c->d_stats, PCR_STATS_PARTIALS * sizeof(pcr_render_stats)) != hipSuccess) {
         pcr_destroy(c);
         return set_err(nullptr, PCR_E_HIP, "could not create stream/events");
     }
     c->stream = c->own_stream;
-    (void)hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream);
     *out = c;
     return PCR_OK;
 }
@@ -582,14 +584,14 @@ int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
     int rc = check_las(c, p);
     if (rc) return rc;
     const int64_t nB = c->las_loaded;
-    if (nB == 0) return PCR_OK;                                // compute_loop_las_cuda.h:107
+    if (nB == 0) { c->stats_partials = 0; return PCR_OK; }     // compute_loop_las_cuda.h:107
     LasArgs a;
     a.p = *p;
     a.s.batches = c->d_xyzb; a.s.xyz12 = c->d_xyz12; a.s.xyz8 = c->d_xyz8; a.s.xyz4 = c->d_xyz4; a.s.num_batches = nB;
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
     a.level = c->d_las_level; a.win = c->d_las_win; a.stats = c->d_stats; a.win_capacity = WIN_PIXELS;
-    HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcr_render_stats), c->stream));
-    hipLaunchKernelGGL(k_las_prepass, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, c->stream, a);
+    c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
+    hipLaunchKernelGGL(k_las_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(k_las_render, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return PCR_OK;
@@ -638,8 +640,16 @@ int pcr_resolve_hqs(pcr_ctx *c, const pcr_render_params *p) { return launch_reso
 int pcr_get_stats(pcr_ctx *c, pcr_render_stats *out)
 {
     if (!c || !out) return PCR_E_ARG;
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_stats, sizeof *out, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    pcr_render_stats part[PCR_STATS_PARTIALS];
+    std::memset(out, 0, sizeof *out);
+    if (c->stats_partials > 0) {
+        HIP_TRY(c, hipMemcpyAsync(part, c->d_stats, (size_t)c->stats_partials * sizeof(pcr_render_stats), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < c->stats_partials; ++i) {
+            out->batches_total += part[i].batches_total; out->batches_culled += part[i].batches_culled;
+            out->points_iterated += part[i].points_iterated; out->batches_double += part[i].batches_double;
+        }
+    }
     return PCR_OK;
 }
 

@@ -80,7 +80,7 @@ struct RenderArgs {
     FrameView f;
     uint32_t *lod;            // [nB]
     uint2 *win;               // [nB] LDS depth-window rectangle per batch: {x0 | y0<<16, w | h<<16}, w == 0: none
-    pcr_render_stats *stats;  // device
+    pcr_render_stats *stats;  // device: one partial record per prepass workgroup
     int variant_hqs;          // LOD expression variant
     int win_capacity;         // pixels the LDS window of the following k_render<MODE> can hold
 };
@@ -104,20 +104,49 @@ __device__ __forceinline__ bool plane_accepts(float x, float y, float z, float w
     return !(d < 0.0f);
 }
 
+// Frame statistics: every prepass workgroup sums its batches in LDS and writes ONE partial record (no global atomics,
+// nothing to zero beforehand); pcr_get_stats adds the partials of the last launch. PCR_STATS_PARTIALS bounds the grid.
+constexpr int PREPASS_THREADS = 256;
+__device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_render_stats *partials)
+{
+    __shared__ unsigned long long s_sum[4];
+    if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    if (mine.batches_total)   atomicAdd(&s_sum[0], (unsigned long long)mine.batches_total);
+    if (mine.batches_culled)  atomicAdd(&s_sum[1], (unsigned long long)mine.batches_culled);
+    if (mine.points_iterated) atomicAdd(&s_sum[2], (unsigned long long)mine.points_iterated);
+    if (mine.batches_double)  atomicAdd(&s_sum[3], (unsigned long long)mine.batches_double);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pcr_render_stats r;
+        r.batches_total = (int64_t)s_sum[0]; r.batches_culled = (int64_t)s_sum[1];
+        r.points_iterated = (int64_t)s_sum[2]; r.batches_double = (int64_t)s_sum[3];
+        partials[blockIdx.x] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // prepass: cull + LOD per batch
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
+__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, pcr_render_stats &st);
+
+__global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.s.num_batches) return;
+    pcr_render_stats st = {0, 0, 0, 0};
+    if (b < a.s.num_batches) lod_prepass_batch(a, b, st);
+    commit_stats(st, a.stats);
+}
+
+__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, pcr_render_stats &st)
+{
     const pcr_gpu_batch g = a.s.batches[b];
     const pcr_render_params &p = a.p;
     const float lm[3] = { (float)g.las_min_x, (float)g.las_min_y, (float)g.las_min_z };      // :336
     const float bmin[3] = { g.min_x - lm[0], g.min_y - lm[1], g.min_z - lm[2] };             // :340
     const float bmax[3] = { g.max_x - lm[0], g.max_y - lm[1], g.max_z - lm[2] };             // :341
 
-    atomicAdd((unsigned long long *)&a.stats->batches_total, 1ull);
+    st.batches_total += 1;
     if (p.enable_frustum_culling) {                                                          // :342-344
         const float *M = p.transform;
 #define T(i) M[((i) % 4) * 4 + ((i) / 4)]
@@ -130,7 +159,7 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
 #undef T
         if (!in) {
             a.lod[b] = LOD_CULLED;
-            atomicAdd((unsigned long long *)&a.stats->batches_culled, 1ull);
+            st.batches_culled += 1;
             return;
         }
     }
@@ -159,8 +188,8 @@ __global__ void __launch_bounds__(256) k_lod_prepass(RenderArgs a)
     npr = min(npr, p.points_per_thread);
     npr = max(npr, 0);
     a.lod[b] = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
-    atomicAdd((unsigned long long *)&a.stats->points_iterated, (unsigned long long)npr * PCR_WORKGROUP_SIZE);
-    if (use_double) atomicAdd((unsigned long long *)&a.stats->batches_double, 1ull);
+    st.points_iterated += (int64_t)npr * PCR_WORKGROUP_SIZE;
+    if (use_double) st.batches_double += 1;
 
     // Screen rectangle of the batch's bounding box: where k_render keeps its LDS copy of the framebuffer. This is
     // only a cache placement hint (points that land outside it take the global path), so it needs no exactness.
@@ -736,14 +765,22 @@ __device__ __forceinline__ uint2 window_rect(const pcr_render_params &p, const f
     return make_uint2(0, 0);
 }
 
-__global__ void __launch_bounds__(256) k_las_prepass(LasArgs a)
+__device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, pcr_render_stats &st);
+
+__global__ void __launch_bounds__(PREPASS_THREADS) k_las_prepass(LasArgs a)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.s.num_batches) return;
+    pcr_render_stats st = {0, 0, 0, 0};
+    if (b < a.s.num_batches) las_prepass_batch(a, b, st);
+    commit_stats(st, a.stats);
+}
+
+__device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, pcr_render_stats &st)
+{
     const pcr_xyz_batch g = a.s.batches[b];
     const pcr_render_params &p = a.p;
     const float bmin[3] = { g.min_x, g.min_y, g.min_z }, bmax[3] = { g.max_x, g.max_y, g.max_z };
-    atomicAdd((unsigned long long *)&a.stats->batches_total, 1ull);
+    st.batches_total += 1;
     if (p.enable_frustum_culling) {                                          // render.cu:153-155
         const float *M = p.transform;
 #define T(i) M[((i) % 4) * 4 + ((i) / 4)]
@@ -756,7 +793,7 @@ __global__ void __launch_bounds__(256) k_las_prepass(LasArgs a)
 #undef T
         if (!in) {
             a.level[b] = -1;
-            atomicAdd((unsigned long long *)&a.stats->batches_culled, 1ull);
+            st.batches_culled += 1;
             return;
         }
     }
@@ -778,7 +815,7 @@ __global__ void __launch_bounds__(256) k_las_prepass(LasArgs a)
     const float px = sqrtf(__fmaf_rn(ddy, ddy, ddx * ddx));
     a.level[b] = px < 100.0f ? 4 : px < 200.0f ? 3 : px < 500.0f ? 2 : px < 10000.0f ? 1 : 0;
     if (b != a.s.num_batches - 1)                                            // the last workgroup returns early (:201-202)
-        atomicAdd((unsigned long long *)&a.stats->points_iterated, (unsigned long long)PCR_POINTS_PER_BATCH);
+        st.points_iterated += PCR_POINTS_PER_BATCH;
     a.win[b] = window_rect(p, bmin, bmax, a.win_capacity);
 }
 
