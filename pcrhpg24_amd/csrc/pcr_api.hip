@@ -487,14 +487,13 @@ int pcr_clear(pcr_ctx *c)
     if (!c) return PCR_E_ARG;
     if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->fb, 0xFF, c->fb_elems * 8, c->stream));      // huffman_hqs.h:267
-    // HuffmanMemIter clears only fb (huffman_mem_iter_cuda.h:250-252); RG/BA are re-zeroed only after a colour pass
-    // (or when the buffers changed hands), which saves two 16.6 MB fills per basic frame at 1080p
-    if (c->accum_dirty) {
-        if (c->rg) HIP_TRY(c, hipMemsetAsync(c->rg, 0, c->fb_elems * 8, c->stream));   // :268
-        if (c->ba) HIP_TRY(c, hipMemsetAsync(c->ba, 0, c->fb_elems * 8, c->stream));   // :269
-        c->accum_dirty = false;
-    }
+    // huffman_hqs.h:267-269. HuffmanMemIter clears only fb (huffman_mem_iter_cuda.h:250-252); RG/BA are re-zeroed only
+    // after a colour pass (or when the buffers changed hands), which saves two 16.6 MB fills per basic frame at 1080p
+    uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
+    if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, c->stream, c->fb, rg, ba, c->fb_elems);
+    HIP_TRY(c, hipGetLastError());
+    c->accum_dirty = false;
     return PCR_OK;
 }
 
