@@ -9,7 +9,7 @@ Workload (BASELINE.json configs[1]): 1e8 synthetic Morton-sorted points, per-bat
 (1526 batches), 1920x1080, basic {depth,colour} atomicMin raster, LOD% = 100 and frustum culling off so
 every point is decoded and rasterized. For N > 1 the scene grows to N x 1e8 points (weak
 scaling), chunks are sharded contiguously over the ranks and every step ends with the RCCL min-merge of
-the partial framebuffers.
+the partial framebuffers (reduce to rank 0, where the frame is resolved; --merge allreduce keeps it everywhere).
 
 A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM.
 Prints ONE JSON line on rank 0.
@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--lod", type=int, default=100, help="LOD percent (uPointFormat); 100 = all 64 points per chain")
     ap.add_argument("--cull", type=int, default=0)
     ap.add_argument("--camera", choices=["overview", "closeup"], default="overview")
+    ap.add_argument("--merge", choices=["reduce", "allreduce"], default="reduce",
+                    help="multi-GPU exchange: min-reduce the partial framebuffers to rank 0 (the display rank) or all-reduce them")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = automatic (bounded)")
@@ -123,15 +125,15 @@ def main():
 
     frame, pipe = None, None
     if use_dist and args.method == "basic" and os.environ.get("PCR_NO_OVERLAP") != "1":
-        pipe = pdist.PipelinedBasicRenderer(ctx, args.width, args.height, dev)   # merge of frame k overlaps render k+1
+        pipe = pdist.PipelinedBasicRenderer(ctx, args.width, args.height, dev, merge=args.merge)   # merge of frame k overlaps render k+1
         step = lambda: pipe.step(p)
     else:
         if use_dist:
             frame = pdist.DeviceFrame(ctx, args.width, args.height, dev)
             frame.bind()
             ctx.clear()
-        step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world)) if args.method == "basic" else \
-               (lambda: pdist.render_hqs_sharded(ctx, frame, p, world))
+        step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world, merge=args.merge)) if args.method == "basic" else \
+               (lambda: pdist.render_hqs_sharded(ctx, frame, p, world, merge=args.merge))
 
     def fence():
         if pipe is not None:
@@ -223,7 +225,7 @@ def main():
                        "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
-                       "parallelism": ("batch-sharded x%d + RCCL min all-reduce%s" % (world, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
+                       "parallelism": ("batch-sharded x%d + RCCL min %s%s" % (world, "reduce to rank 0" if args.merge == "reduce" else "all-reduce", " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

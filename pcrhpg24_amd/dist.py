@@ -3,9 +3,11 @@ path has — merging the partial framebuffers. No reference counterp
 is single-GPU: src/main.cpp:61); correctness rests on `min` / `+` being associative and commutative on
 the packed 64-bit words, which makes the merged result bit-identical to a single-GPU render.
 
-    basic :  render shard -> all-reduce MIN over the u64 framebuffer
+    basic :  render shard -> reduce MIN of the u64 framebuffer to the display rank (0) -> resolve there
     HQS   :  depth pass  -> all-reduce MIN (every rank then tests against the GLOBAL depth)
-             colour pass -> all-reduce SUM over RG and BA -> resolve
+             colour pass -> reduce SUM of RG|BA (one buffer) to the display rank -> resolve there
+A reduce moves half the bytes of an all-reduce over the point-to-point xGMI links; `merge="allreduce"` keeps the
+finished frame on every rank instead.
 
 torch.distributed is the transport (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests). It exposes signed int64 only, so the u64 min is computed as a signed min on sign-flipped words
@@ -37,6 +39,24 @@ def allreduce_min_u64_numpy(fb: np.ndarray, group=None) -> np.ndarray:
     return fb
 
 
+def reduce_min_u64_numpy(fb: np.ndarray, dst: int = 0, group=None) -> np.ndarray:
+    """CPU path (gloo): u64 min reduce to rank `dst`; other ranks' buffers are left unspecified (as NCCL does)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy((fb ^ SIGN).view(np.int64))
+    dist.reduce(t, dst=dst, op=dist.ReduceOp.MIN, group=group)
+    fb[:] = t.numpy().view(np.uint64) ^ SIGN
+    return fb
+
+
+def reduce_sum_u64_numpy(acc: np.ndarray, dst: int = 0, group=None) -> np.ndarray:
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(acc.view(np.int64))
+    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return acc
+
+
 def allreduce_sum_u64_numpy(acc: np.ndarray, group=None) -> np.ndarray:
     import torch
     import torch.distributed as dist
@@ -52,11 +72,13 @@ class DeviceFrame:
         import torch
         from ._native import fb_elems
         n = fb_elems(width, height)
+        n2 = (n + 1) & ~1                          # keeps BA 16-byte aligned behind RG
         self.ctx = ctx
         self.device = device
         self.fb = torch.empty(n, dtype=torch.int64, device=device)
-        self.rg = torch.zeros(n, dtype=torch.int64, device=device)
-        self.ba = torch.zeros(n, dtype=torch.int64, device=device)
+        self.acc = torch.zeros(2 * n2, dtype=torch.int64, device=device)   # RG | BA: one collective for both
+        self.rg = self.acc[:n]
+        self.ba = self.acc[n2:n2 + n]
 
     def bind(self, stream=None):
         """Make this frame the context's render target; pcr work goes to `stream` (default: torch's current)."""
@@ -73,8 +95,22 @@ class DeviceFrame:
 
     def allreduce_sum(self, group=None):
         import torch.distributed as dist
-        dist.all_reduce(self.rg, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(self.ba, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=group)
+
+    def reduce_min(self, dst: int = 0, group=None) -> bool:
+        """u64 min reduce to rank `dst`; returns whether this rank holds the merged frame afterwards."""
+        import torch.distributed as dist
+        self.ctx.flip_sign()
+        dist.reduce(self.fb, dst=dst, op=dist.ReduceOp.MIN, group=group)
+        mine = dist.get_rank(group) == dst
+        if mine:
+            self.ctx.flip_sign()                    # the other ranks' copies are cleared by the next frame anyway
+        return mine
+
+    def reduce_sum(self, dst: int = 0, group=None) -> bool:
+        import torch.distributed as dist
+        dist.reduce(self.acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        return dist.get_rank(group) == dst
 
     def release(self):
         self.ctx.synchronize()
@@ -82,24 +118,35 @@ class DeviceFrame:
         self.ctx.set_stream(0)
 
 
-def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None):
-    """One frame of the basic method on this rank's shard + the merge, all on one stream. Enqueue only."""
+def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None, merge: str = "reduce"):
+    """One frame of the basic method on this rank's shard + the merge, all on one stream. Enqueue only.
+    merge="reduce": the finished frame (and its resolve) live on rank 0; "allreduce": on every rank."""
     ctx.clear()
     ctx.render_basic(params)
+    final = True
     if frame is not None:
-        frame.allreduce_min(group)
-    ctx.resolve_basic(params)
+        if merge == "reduce":
+            final = frame.reduce_min(0, group)
+        else:
+            frame.allreduce_min(group)
+    if final:
+        ctx.resolve_basic(params)
 
 
-def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None):
+def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None, merge: str = "reduce"):
     ctx.clear()
     ctx.render_hqs_depth(params)
     if frame is not None:
-        frame.allreduce_min(group)          # global depth before the 1 % test
+        frame.allreduce_min(group)          # global depth before the 1 % test: every rank needs it
     ctx.render_hqs_color(params)
+    final = True
     if frame is not None:
-        frame.allreduce_sum(group)
-    ctx.resolve_hqs(params)
+        if merge == "reduce":
+            final = frame.reduce_sum(0, group)
+        else:
+            frame.allreduce_sum(group)
+    if final:
+        ctx.resolve_hqs(params)
 
 
 class PipelinedBasicRenderer:
@@ -108,12 +155,12 @@ class PipelinedBasicRenderer:
     rasterized into the other of two framebuffers on the compute stream. HIP events order the two streams; results
     are the same as the one-stream form, one frame later."""
 
-    def __init__(self, ctx, width: int, height: int, device, group=None):
+    def __init__(self, ctx, width: int, height: int, device, group=None, merge: str = "reduce"):
         import torch
-        self.ctx, self.device, self.group = ctx, device, group
+        self.ctx, self.device, self.group, self.merge = ctx, device, group, merge
         self.frames = [DeviceFrame(ctx, width, height, device), DeviceFrame(ctx, width, height, device)]
         self.compute = torch.cuda.Stream(device)
-        self.comm = torch.cuda.Stream(device)
+        self.comm = torch.cuda.Stream(device, priority=-1)   # its small kernels should not queue behind a frame's 1526 workgroups
         self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
         self.merged = [torch.cuda.Event(), torch.cuda.Event()]
         self.k = 0
@@ -132,8 +179,9 @@ class PipelinedBasicRenderer:
         self.comm.wait_event(self.rendered[i])
         with torch.cuda.stream(self.comm):             # RCCL orders itself against torch's current stream
             f.bind(self.comm)
-            f.allreduce_min(self.group)
-            self.ctx.resolve_basic(params)
+            final = f.reduce_min(0, self.group) if self.merge == "reduce" else (f.allreduce_min(self.group) or True)
+            if final:
+                self.ctx.resolve_basic(params)
             self.merged[i].record(self.comm)
         self.k += 1
 

@@ -37,8 +37,13 @@ def _worker(rank, world, port, total, out_dir):
         d, _ = of.render_hqs_depth(cam, first=first, count=count)
         pdist.allreduce_min_u64_numpy(d)
         rg, ba, _ = of.render_hqs_color(cam, d, first=first, count=count)
+        rg_root, ba_root = rg.copy(), ba.copy()
         pdist.allreduce_sum_u64_numpy(rg); pdist.allreduce_sum_u64_numpy(ba)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fb=fb, d=d, rg=rg, ba=ba)
+        # reduce-to-root forms (what bench.py uses: the finished frame lives on the display rank)
+        fb_root, _ = of.render_basic(cam, first=first, count=count)
+        pdist.reduce_min_u64_numpy(fb_root, dst=0)
+        pdist.reduce_sum_u64_numpy(rg_root, dst=0); pdist.reduce_sum_u64_numpy(ba_root, dst=0)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fb=fb, d=d, rg=rg, ba=ba, fb_root=fb_root, rg_root=rg_root, ba_root=ba_root)
     finally:
         dist.destroy_process_group()
 
@@ -66,6 +71,8 @@ def test_two_ranks_reproduce_single_process_render(tmp_path):
         z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         assert np.array_equal(z["fb"], fb), "merged basic framebuffer differs from the single-process render"
         assert np.array_equal(z["d"], d) and np.array_equal(z["rg"], rg) and np.array_equal(z["ba"], ba)
+        if rank == 0:
+            assert np.array_equal(z["fb_root"], fb) and np.array_equal(z["rg_root"], rg) and np.array_equal(z["ba_root"], ba)
 
 
 def test_shard_upload_view_equals_the_global_stream_segment():
