@@ -106,16 +106,9 @@ def main():
         ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
     if world > 1:
         # shard boundary: the words that follow this shard in the global stream
-        enc_h, sep_h = hf.head_words(0)
-        head = torch.zeros(2 + 1024 + 256, dtype=torch.int32, device=dev)
-        head[0], head[1] = len(enc_h), len(sep_h)
-        head[2:2 + len(enc_h)] = torch.from_numpy(enc_h.view("int32").copy()).to(dev)
-        head[2 + 1024:2 + 1024 + len(sep_h)] = torch.from_numpy(sep_h.copy()).to(dev)
-        heads = [torch.empty_like(head) for _ in range(world)]
-        dist.all_gather(heads, head)
-        if rank + 1 < world:
-            nx = heads[rank + 1].cpu().numpy()
-            ctx.upload_tail(nx[2:2 + nx[0]].view("uint32"), nx[2 + 1024:2 + 1024 + nx[1]])
+        nxt = pdist.exchange_shard_heads(*hf.head_words(0), dev)
+        if nxt is not None:
+            ctx.upload_tail(*nxt)
     ctx.synchronize()
     t_load = time.time() - t0
 

@@ -65,6 +65,28 @@ def allreduce_sum_u64_numpy(acc: np.ndarray, group=None) -> np.ndarray:
     return acc
 
 
+def exchange_shard_heads(head_enc: np.ndarray, head_sep: np.ndarray, device, group=None):
+    """Every rank contributes the first words of ITS first batch (HuffmanFile.head_words(first)); returns the head words
+    of the rank that follows this one in the global stream — what pcr_upload_tail needs so that the reference's tail
+    over-reads see the same bytes as on one GPU — or None on the last rank. One small all_gather."""
+    import torch
+    import torch.distributed as dist
+    from .host import ENCODED_PAD_WORDS, SEPARATE_PAD_WORDS
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ne, ns = min(len(head_enc), ENCODED_PAD_WORDS), min(len(head_sep), SEPARATE_PAD_WORDS)
+    head = np.zeros(2 + ENCODED_PAD_WORDS + SEPARATE_PAD_WORDS, np.int32)
+    head[0], head[1] = ne, ns
+    head[2:2 + ne] = np.asarray(head_enc[:ne], np.uint32).view(np.int32)
+    head[2 + ENCODED_PAD_WORDS:2 + ENCODED_PAD_WORDS + ns] = np.asarray(head_sep[:ns], np.int32)
+    mine = torch.from_numpy(head).to(device)
+    heads = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(heads, mine, group=group)
+    if rank + 1 >= world:
+        return None
+    nx = heads[rank + 1].cpu().numpy()
+    return (nx[2:2 + nx[0]].copy().view(np.uint32), nx[2 + ENCODED_PAD_WORDS:2 + ENCODED_PAD_WORDS + nx[1]].copy())
+
+
 class DeviceFrame:
     """Framebuffers owned by torch (so RCCL can reduce them in place) and lent to a pcr context."""
 

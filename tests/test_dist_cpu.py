@@ -48,6 +48,44 @@ def _worker(rank, world, port, total, out_dir):
         dist.destroy_process_group()
 
 
+def _heads_worker(rank, world, port, total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank encodes only its own chunk range, as bench.py does
+        chunk = 65536 * 2
+        nchunks = -(-total // chunk)
+        c0, cn = pdist.shard_range(nchunks, world, rank)
+        first = c0 * chunk
+        image, _ = P.synth_encode(total, scenes.SEED, first, min(total, (c0 + cn) * chunk) - first, chunk, 2)
+        hf = P.HuffmanFile(image)
+        nxt = pdist.exchange_shard_heads(*hf.head_words(0), "cpu")
+        if nxt is None:
+            np.savez(os.path.join(out_dir, f"heads{rank}.npz"), none=np.ones(1))
+        else:
+            np.savez(os.path.join(out_dir, f"heads{rank}.npz"), enc=nxt[0], sep=nxt[1])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_heads_exchange_delivers_the_followers_first_words(tmp_path):
+    total, world, chunk = 700_000, 3, 65536 * 2          # 6 chunks -> 2 + 2 + 2
+    mp.spawn(_heads_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    whole, _ = P.synth_encode(total, scenes.SEED, chunk_points=chunk, nthreads=2)
+    hf = P.HuffmanFile(whole)
+    per_chunk = chunk // 65536
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"heads{rank}.npz"))
+        if rank == world - 1:
+            assert "none" in z
+            continue
+        c0, cn = pdist.shard_range(6, world, rank)
+        enc, sep = hf.head_words((c0 + cn) * per_chunk)                 # first batch of the following rank in the global file
+        assert np.array_equal(z["enc"], enc) and np.array_equal(z["sep"], sep)
+        assert z["enc"].dtype == np.uint32 and z["sep"].dtype == np.int32
+
+
 def test_shard_range_partitions_exactly():
     for n in (1, 7, 31, 1526, 30518):
         for w in (1, 2, 3, 8):
