@@ -142,8 +142,8 @@ int   pcr_flip_sign(pcr_ctx *ctx);
 int pcr_timing_begin(pcr_ctx *ctx);
 int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
 
-/* Algorithmic HBM bytes one render_basic launch over the loaded stream must move at least once
- * (encoded + separate + cluster + per-batch side data), for roofline accounting. */
+/* Algorithmic HBM bytes of one render launch over the loaded stream, SURVEY 8d's B_dec x points: every byte of the
+ * compressed representation once (encoded + separate + cluster prefix + per batch 160 + 12 288 + 4 096 + 32 768). */
 int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *ctx);
 
 #ifdef __cplusplus

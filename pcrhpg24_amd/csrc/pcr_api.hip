@@ -456,9 +456,10 @@ int64_t pcr_points_loaded(const pcr_ctx *c) { return c ? c->points_loaded : 0; }
 int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
 {
     if (!c || !c->stream_open) return 0;
-    // every compressed byte once + per-batch side data (GPUBatch + start values + escape prefix + table
-    // as k_render reads it: 16 KiB of packed entries) + cluster prefix
-    const int64_t per_batch = 160 + 12288 + 4096 + 16384 + 128;
+    // SURVEY 8d, B_dec: every byte of the compressed representation once = encoded + separate + cluster prefix (128 B per
+    // batch) + per-batch side data as the file holds it (GPUBatch 160 + start values 12 288 + escape prefix 4 096 + the
+    // two int32 decoder-table arrays 32 768). k_render itself reads the table as 16 KiB of packed entries.
+    const int64_t per_batch = 128 + 160 + 12288 + 4096 + 32768;
     return c->enc_ptr * 4 + c->sep_ptr * 4 + c->batches_loaded * per_batch;
 }
 
