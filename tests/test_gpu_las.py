@@ -148,3 +148,19 @@ def test_las_argument_errors(renderer):
     assert ctx.stats()["points_iterated"] == 0
     assert (ctx.read_framebuffer() == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
     ctx.las_unload()
+
+
+def test_las_random_cameras(renderer, cloud):
+    """Seeded random orbit cameras over both point orders: all three precision levels, culling on and off."""
+    pts, q = cloud
+    _load(renderer, pts)
+    rng = np.random.default_rng(77)
+    levels = set()
+    for _ in range(16):
+        yaw, pitch = rng.uniform(-np.pi, np.pi), rng.uniform(-1.5, 0.3)
+        radius = float(10.0 ** rng.uniform(0.3, 4.2))
+        target = (rng.uniform(-200, 1200), rng.uniform(-200, 1200), rng.uniform(-50, 150))
+        p = scenes.with_flags(P.camera_orbit(yaw, pitch, radius, target, W, H, fovy=float(rng.uniform(10, 120))), cull=int(rng.integers(0, 2)))
+        _check(renderer.ctx, q, p)
+        levels |= {oracle.las_level(q[0][b], p) for b in range(len(q[0]))}
+    assert {0, 1, 2} <= levels

@@ -176,3 +176,21 @@ def test_error_behaviour(renderer, stream200k):
     with pytest.raises(P.PcrError, match="image size"):
         ctx.render_basic(q)
     ctx.stream_unload()
+
+
+def test_random_cameras_and_flags(renderer, stream2m):
+    """Seeded random orbit cameras (near/inside/far, any direction), LOD and flag combinations: every frame of both
+    methods equals the oracle's bit for bit."""
+    nb, of = stream2m
+    _load(renderer, nb)
+    rng = np.random.default_rng(2024)
+    for k in range(24):
+        yaw, pitch = rng.uniform(-np.pi, np.pi), rng.uniform(-1.5, 0.3)
+        radius = float(10.0 ** rng.uniform(0.3, 4.2))                      # 2 m .. 16 km
+        target = (rng.uniform(-200, 1200), rng.uniform(-200, 1200), rng.uniform(-50, 150))
+        p = P.camera_orbit(yaw, pitch, radius, target, W, H, fovy=float(rng.uniform(10, 120)))
+        p = scenes.with_flags(p, lod_percent=int(rng.choice([0, 3, 10, 50, 100])), cull=int(rng.integers(0, 2)),
+                              show_num_points=int(rng.integers(0, 2)), colorize_chunks=int(rng.integers(0, 2)))
+        _check_basic(renderer.ctx, of, p)
+        if k % 3 == 0:
+            _check_hqs(renderer.ctx, of, p)
