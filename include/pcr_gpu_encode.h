@@ -18,7 +18,8 @@ extern "C" {
 #endif
 
 /* x, y, z, color: host arrays of n points (int32 LAS coordinates, 0x00BBGGRR). flags: PCR_ENCODE_MORTON_SORT |
- * PCR_ENCODE_PAD_TAILS. chunk_points <= 0: PCR_DEFAULT_CHUNK_POINTS (it must be a multiple of 65 536).
+ * PCR_ENCODE_PAD_TAILS. chunk_points <= 0: PCR_DEFAULT_CHUNK_POINTS (it must be a multiple of 65 536 and at most 1024 x 65 536;
+ * device scratch is ~16 MB per batch of a chunk).
  * *out_bytes is malloc'ed; release with pcr_gpu_encode_free. Work is enqueued on the context's stream and the call
  * returns when the image is complete. Returns PCR_OK or a negative PCR_E_* (message: pcr_last_error(ctx)). */
 int  pcr_gpu_encode_points(pcr_ctx *ctx, const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color,

@@ -379,6 +379,8 @@ extern "C" int pcr_gpu_encode_points(pcr_ctx *c, const int32_t *x, const int32_t
     if (n <= 0) return set_err(c, PCR_E_ARG, "no points");
     if (chunk_points <= 0) chunk_points = PCR_DEFAULT_CHUNK_POINTS;
     if (chunk_points % NPB) return set_err(c, PCR_E_ARG, "chunk_points must be a multiple of %d", NPB);
+    if (chunk_points / NPB > 1024)      // scratch is sized per chunk (16 MB per batch) and the sorts index it with 32-bit ints
+        return set_err(c, PCR_E_ARG, "chunk_points must not exceed %d (1024 batches)", 1024 * NPB);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const bool sort = (flags & PCR_ENCODE_MORTON_SORT) != 0;

@@ -92,5 +92,7 @@ def test_argument_errors(ctx):
     x = np.zeros(4, np.int32)
     with pytest.raises(P.PcrError, match="multiple of 65536"):
         ctx.gpu_encode_points(x, x, x, x.astype(np.uint32), P.synth_las_info(1), chunk_points=1000)
+    with pytest.raises(P.PcrError, match="must not exceed"):
+        ctx.gpu_encode_points(x, x, x, x.astype(np.uint32), P.synth_las_info(1), chunk_points=65536 * 2000)
     with pytest.raises(P.PcrError, match="no points"):
         ctx.gpu_encode_points(x[:0], x[:0], x[:0], x[:0].astype(np.uint32), P.synth_las_info(1))
