@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <memory>
 #include <mutex>
@@ -35,7 +36,42 @@ struct Debug {                                  // include/Debug.h:21-30 (flags 
     inline static bool frustumCullingEnabled = true;
     inline static bool colorizeChunks = false;
     inline static bool showNumPoints = false;
+    inline static bool saveDepthMap = false;            // include/Debug.h: one-shot, cleared after the dump
+    inline static std::string depthMapPath = "depth.exr";   // the reference writes "out/depth.exr" (huffman_hqs.h:235)
 };
+
+// huffman_hqs.h:71-113 saves the depth map through tinyexr: one FLOAT channel "Z". Same file kind, written directly:
+// OpenEXR 2 scanline file, no compression, increasing-Y line order.
+inline bool saveSingleChannelEXR(const char *filename, const float *depthData, int width, int height)
+{
+    std::vector<uint8_t> f;
+    auto raw = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; f.insert(f.end(), b, b + n); };
+    auto i32 = [&](int32_t v) { raw(&v, 4); };
+    auto str = [&](const char *z) { raw(z, std::strlen(z) + 1); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { str(name); str(type); i32(size); };
+    const uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+    raw(magic, 8);
+    attr("channels", "chlist", 2 + 16 + 1);
+    str("Z"); i32(2 /* FLOAT */); { const uint8_t plin[4] = {0, 0, 0, 0}; raw(plin, 4); } i32(1); i32(1);
+    { const uint8_t end = 0; raw(&end, 1); }
+    attr("compression", "compression", 1); { const uint8_t none = 0; raw(&none, 1); }
+    const int32_t box[4] = {0, 0, width - 1, height - 1};
+    attr("dataWindow", "box2i", 16); raw(box, 16);
+    attr("displayWindow", "box2i", 16); raw(box, 16);
+    attr("lineOrder", "lineOrder", 1); { const uint8_t incy = 0; raw(&incy, 1); }
+    const float one = 1.0f, zero2[2] = {0.0f, 0.0f};
+    attr("pixelAspectRatio", "float", 4); raw(&one, 4);
+    attr("screenWindowCenter", "v2f", 8); raw(zero2, 8);
+    attr("screenWindowWidth", "float", 4); raw(&one, 4);
+    { const uint8_t end = 0; raw(&end, 1); }
+    const uint64_t table = f.size(), line = 8 + (uint64_t)width * 4;
+    for (int y = 0; y < height; ++y) { const uint64_t off = table + 8ull * height + line * y; raw(&off, 8); }
+    for (int y = 0; y < height; ++y) { i32(y); i32(width * 4); raw(depthData + (size_t)y * width, (size_t)width * 4); }
+    std::ofstream o(filename, std::ios::binary);
+    o.write((const char *)f.data(), (std::streamsize)f.size());
+    return (bool)o;
+}
+
 
 struct Renderer {
     int width = 1920, height = 1080;            // src/Renderer.cpp:142-143
@@ -68,6 +104,21 @@ struct Renderer {
         return p;
     }
 };
+
+// huffman_hqs.h:217-237: depth of every covered pixel as float, image flipped vertically, empty pixels 0
+inline bool dumpDepthMap(Renderer *r, pcr_ctx *ctx, int width, int height, const std::string &path)
+{
+    std::vector<uint64_t> fb_host((size_t)width * height);
+    r->check(pcr_read_framebuffer(ctx, fb_host.data(), fb_host.size()), "pcr_read_framebuffer");
+    std::vector<float> depthmap((size_t)width * height, 0.0f);
+    for (int i = 0; i < height; ++i)
+        for (int j = 0; j < width; ++j) {
+            const uint32_t value = (uint32_t)(fb_host[(size_t)i * width + j] >> 32);
+            if (value == 0xFFFFFFFFu) continue;
+            std::memcpy(&depthmap[(size_t)(height - i - 1) * width + j], &value, 4);
+        }
+    return saveSingleChannelEXR(path.c_str(), depthmap.data(), width, height);
+}
 
 enum ResourceState { UNLOADED, LOADING, LOADED, UNLOADING };   // Resources.h:20-25
 
@@ -274,6 +325,10 @@ struct HuffmanHQS : HuffmanMethodBase {
         r->check(pcr_clear(r->ctx), "pcr_clear");
         r->check(pcr_render_hqs_depth(r->ctx, &lastParams), "pcr_render_hqs_depth");
         r->check(pcr_render_hqs_color(r->ctx, &lastParams), "pcr_render_hqs_color");
+        if (Debug::saveDepthMap) {                          // huffman_hqs.h:217-237
+            dumpDepthMap(r, r->ctx, r->width, r->height, Debug::depthMapPath);
+            Debug::saveDepthMap = false;
+        }
         r->check(pcr_resolve_hqs(r->ctx, &lastParams), "pcr_resolve_hqs");
     }
 };

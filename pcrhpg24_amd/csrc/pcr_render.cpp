@@ -4,7 +4,7 @@
 //   pcr_render <file.huffman> [--method huffman_mem_iter_cuda|huffman_hqs] [--size WxH]
 //   pcr_render <file.las>      --method loop_las_cuda                      [--size WxH]
 //              [--camera yaw pitch radius tx ty tz] [--lod 0.1] [--cull 0|1] [--frames N]
-//              [--dump-fb fb.u64] [--dump-rgba out.ppm]
+//              [--dump-fb fb.u64] [--dump-rgba out.ppm] [--dump-depth depth.exr]   (depth: huffman_hqs only, huffman_hqs.h:217-237)
 // Prints one JSON line: batches, frames needed to load, ms of the last frame, FNV-1a of the u64 framebuffer.
 #include <chrono>
 #include <cstdlib>
@@ -26,7 +26,7 @@ static uint64_t fnv1a(const void *p, size_t n)
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::fprintf(stderr, "usage: pcr_render <file.huffman> [options]\n"); return 2; }
-    std::string path = argv[1], method = "huffman_mem_iter_cuda", dump_fb, dump_rgba;
+    std::string path = argv[1], method = "huffman_mem_iter_cuda", dump_fb, dump_rgba, dump_depth;
     int w = 1920, h = 1080, frames = 0;
     // src/main.cpp:192-218 default setting ("morrobay" overview)
     double cam[6] = {-0.15, -0.57, 3166.32, 2239.05, 1713.63, -202.02};
@@ -41,6 +41,7 @@ int main(int argc, char **argv)
         else if (a == "--frames") { need(1); frames = std::atoi(argv[++i]); }
         else if (a == "--dump-fb") { need(1); dump_fb = argv[++i]; }
         else if (a == "--dump-rgba") { need(1); dump_rgba = argv[++i]; }
+        else if (a == "--dump-depth") { need(1); dump_depth = argv[++i]; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
@@ -80,6 +81,7 @@ int main(int argc, char **argv)
             if (frames > 0 ? n >= frames && loaded : loaded) break;
             if (n > 100000) throw std::runtime_error("loader made no progress");
         }
+        if (!dump_depth.empty()) { Debug::saveDepthMap = true; Debug::depthMapPath = dump_depth; }
         selected->render(&renderer);   // one steady-state frame with everything resident
         std::vector<uint64_t> fb((size_t)w * h);
         renderer.check(pcr_read_framebuffer(renderer.ctx, fb.data(), fb.size()), "pcr_read_framebuffer");

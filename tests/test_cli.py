@@ -89,6 +89,53 @@ def test_render_cli_matches_oracle(tmp_path, method):
     assert (tmp_path / "o.ppm").stat().st_size > W * H * 3
 
 
+def read_single_channel_exr(path):
+    """Minimal reader for what saveSingleChannelEXR writes: scanline OpenEXR, one FLOAT channel, no compression."""
+    b = open(path, "rb").read()
+    assert b[:4] == bytes([0x76, 0x2f, 0x31, 0x01]) and struct.unpack_from("<I", b, 4)[0] == 2
+    o, attrs = 8, {}
+    while b[o] != 0:
+        e = b.index(0, o); name = b[o:e].decode(); o = e + 1
+        e = b.index(0, o); typ = b[o:e].decode(); o = e + 1
+        size = struct.unpack_from("<i", b, o)[0]; o += 4
+        attrs[name] = (typ, b[o:o + size]); o += size
+    o += 1
+    assert attrs["compression"][1] == b"\x00" and attrs["lineOrder"][1] == b"\x00"
+    assert attrs["channels"][1][:2] == b"Z\x00" and struct.unpack_from("<i", attrs["channels"][1], 2)[0] == 2
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    offs = struct.unpack_from("<%dQ" % h, b, o)
+    img = np.zeros((h, w), np.float32)
+    for y in range(h):
+        yy, n = struct.unpack_from("<2i", b, offs[y])
+        assert yy == y and n == 4 * w
+        img[y] = np.frombuffer(b, "<f4", w, offs[y] + 8)
+    return img
+
+
+@pytest.mark.gpu
+def test_render_cli_depth_dump(tmp_path):
+    """--dump-depth: the reference's Debug::saveDepthMap path (huffman_hqs.h:217-237): depth floats, image flipped, 0 = empty."""
+    build.build_tools()
+    image, _ = scenes.synth_stream(2_000_000)
+    path = tmp_path / "scene.huffman"
+    path.write_bytes(bytes(image.view()))
+    W, H = 640, 360
+    cam = ["-0.15", "-0.57", "1500", "500", "500", "40"]
+    res = subprocess.run([build.RENDER_BIN, str(path), "--method", "huffman_hqs", "--size", f"{W}x{H}", "--camera", *cam,
+                          "--lod", "0.1", "--dump-depth", str(tmp_path / "depth.exr")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    img = read_single_channel_exr(tmp_path / "depth.exr")
+    assert img.shape == (H, W)
+    of = oracle.OracleFile(image.view())
+    p = P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), W, H)
+    ofb, _ = of.render_hqs_depth(p)
+    d = (ofb[:W * H] >> np.uint64(32)).astype(np.uint32)
+    exp = np.where(d == 0xFFFFFFFF, np.uint32(0), d).view(np.float32).reshape(H, W)[::-1]
+    assert np.array_equal(img.view(np.uint32), exp.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_render_cli_loop_las_cuda_matches_oracle(tmp_path):
     """pcr_render <file.las> --method loop_las_cuda: C++ ComputeLasData + ComputeLoopLasCUDA against the oracle."""
