@@ -595,24 +595,26 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
                 uint32_t biased = e >> TE_VALUE_SHIFT;                      // value + TE_BIAS; the bias leaves with the delta add below
                 if ((int32_t)e < 0) {                                       // escape or wide
-                    int32_t val;
                     if (!generic_slow) {                                    // (uniform) every such entry is an escape whose word is in the pool
-                        val = s_esc[sp] - (int32_t)TE_BIAS;                 // (folds with the + TE_BIAS below)
-                        ++sp;
-                    } else if (e & TE_ESCAPE) {                             // :438
-                        if (sp < esc_lds) {
-                            val = s_esc[sp] - (int32_t)TE_BIAS;
-                        } else {
-                            // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
-                            val = sep_load(sp);
-                            asm volatile("; escape word from global memory %0" : "+v"(val));
-                        }
+                        biased = (uint32_t)s_esc[sp];                       // the pool holds value + TE_BIAS; needed only by the delta add
                         ++sp;
                     } else {
-                        val = tvalues[toff >> 2];
-                        asm volatile("; wide table value from global memory %0" : "+v"(val));
+                        int32_t val;
+                        if (e & TE_ESCAPE) {                                // :438
+                            if (sp < esc_lds) {
+                                val = s_esc[sp] - (int32_t)TE_BIAS;
+                            } else {
+                                // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
+                                val = sep_load(sp);
+                                asm volatile("; escape word from global memory %0" : "+v"(val));
+                            }
+                            ++sp;
+                        } else {
+                            val = tvalues[toff >> 2];
+                            asm volatile("; wide table value from global memory %0" : "+v"(val));
+                        }
+                        biased = (uint32_t)val + TE_BIAS;
                     }
-                    biased = (uint32_t)val + TE_BIAS;
                 }
                 dec[j] = biased;
 #ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
