@@ -351,7 +351,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
             sft += 32;
         }
         ep += __popc(mh);                                   // :450
-        if (ep >= next_cross) {                             // same ring protocol as described in k_render's history
+        if (ep >= next_cross) {
+            // My half of the wave has consumed the ring's older chunk (a step takes at most 32 words, so every refill
+            // stays inside the two resident chunks): overwrite it with the staged chunk and fetch the chunk after that.
+            // DS operations of a wave execute in order; the fences below only stop the compiler from reordering.
             reinterpret_cast<uint2 *>(ring + ((next_cross + CHUNK_WORDS) & (RING_WORDS - 1)))[lane32] = stage;
             stage = enc_load2(cbase + next_cross + 2 * CHUNK_WORDS + lane32 * 2);
             next_cross += CHUNK_WORDS;
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
     const uint32_t wpix = ww * wh;                          // 0: no window for this batch
     const uint32_t W = (uint32_t)a.p.width;
-    // colour pass layout of the same 20 KiB: sums in the framebuffer's own packed format + the depth to test against
+    // colour pass layout of the same 36 KiB: sums in the framebuffer's own packed format + the depth to test against
     unsigned long long *const s_rg = s_win, *const s_ba = s_win + WIN_PIXELS_HQS;
     uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * WIN_PIXELS_HQS);
     {   // snapshot of the rectangle, all loads of a thread in flight together (a stale value is a valid start)
@@ -562,7 +565,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const float *M = a.p.transform;
     const float fw = (float)a.p.width, fh = (float)a.p.height;
 
-    __syncthreads();        // table, ring, escapes and window are visible
+    __syncthreads();        // table, escapes and window are visible
 
 #ifdef PCR_EXP_PROLOGUE_ONLY   /* experiment only: cost of the per-batch set-up and the window merge (results are wrong) */
     const int npr_run = a.p.reserved == 12345 ? npr : 0;
