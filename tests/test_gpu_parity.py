@@ -194,3 +194,42 @@ def test_random_cameras_and_flags(renderer, stream2m):
         _check_basic(renderer.ctx, of, p)
         if k % 3 == 0:
             _check_hqs(renderer.ctx, of, p)
+
+
+def test_progressive_loading_frames_equal_the_truncated_stream(renderer):
+    """Frames drawn while the resource is still loading (HuffmanLasLoader.cpp:301-313 hands over <= 100 records per
+    frame): after k batches the image equals the oracle's render of the file cut after k batches (the last loaded
+    batch's tail over-reads see the zero pad), and once the rest arrives that batch is re-walked and the frame equals
+    the whole file's."""
+    import struct
+    nb, st = P.synth_encode(16_000_000, scenes.SEED, nthreads=8)            # 245 batches -> tasks of 100, 100, 45
+    hf = P.HuffmanFile(nb)
+    assert hf.numBatches == 245
+
+    def truncated(k):
+        h = hf.header(0, k)
+        return (struct.pack("<5q", h.num_points, h.num_batches, h.encoded_bytes, h.separate_bytes, h.cluster_bytes)
+                + hf.batch_data_sizes[:k].tobytes() + b"".join(bytes(hf.blob(b)) for b in range(k)))
+
+    P.Runtime.reset()
+    if renderer.ctx.batches_loaded:
+        renderer.ctx.stream_unload()
+    las = P.HuffmanLasData.create(nb)
+    m = P.HuffmanMemIter(renderer, las)
+    renderer.set_camera(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0))
+    P.Debug.LOD, P.Debug.frustumCullingEnabled = 1.0, False
+    try:
+        m.update(renderer)
+        seen = []
+        for _ in range(4):
+            m.render(renderer)
+            k = las.numBatchesLoaded
+            seen.append(k)
+            of = oracle.OracleFile(truncated(k)) if k < hf.numBatches else oracle.OracleFile(nb.view())
+            ofb, ost = of.render_basic(m.last_params, nthreads=8)
+            assert renderer.ctx.stats() == ost
+            assert np.array_equal(renderer.ctx.read_framebuffer(full=True), ofb), f"frame with {k} batches loaded"
+        assert seen == [100, 200, 245, 245]
+    finally:
+        P.Debug.LOD, P.Debug.frustumCullingEnabled = 0.1, True
+        las.unload(renderer)
