@@ -637,6 +637,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
         continue;
 #endif
+        // second half of rasterize() for point i-1: its framebuffer word has been in flight during this point's decode.
+        // Done before point i is projected so that the projection can write the pending registers in place.
+        if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, i - 1);
         float x, y, z;
         if (use_double) {                                                   // :459-461
             x = (float)__fma_rn((double)px, sx, ox);
@@ -688,8 +691,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         if (pix == 0x12345678u || widx == 0x123456u) a.f.fb[tid] = __float_as_uint(qw);
         continue;
 #endif
-        // second half for point i-1, whose framebuffer word has been in flight since the previous iteration
-        if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, i - 1);
         pend_pix = pix;
         pend_widx = widx;
         pend_depth = __float_as_uint(qw);                                   // :287
