@@ -266,6 +266,17 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
     return (sel & 2u) ? hi : lo;
 }
 
+// Row/column of linear index i in a window of width ww (i < 2^23): one float multiply and a correction of at most one
+// row instead of a 32-bit integer division (which costs ~25 VALU on this hardware and sat in every set-up and merge).
+__device__ __forceinline__ void window_row_col(uint32_t i, uint32_t ww, float inv_ww, uint32_t &y, uint32_t &x)
+{
+    y = (uint32_t)((float)i * inv_ww);
+    int32_t r = (int32_t)(i - y * ww);
+    if (r < 0) { --y; r += (int32_t)ww; }
+    else if (r >= (int32_t)ww) { ++y; r -= (int32_t)ww; }
+    x = (uint32_t)r;
+}
+
 // One packed dword per table key (layout above): value and length of render.cu:435-439 in a single LDS read.
 __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lbyte)
 {
@@ -426,6 +437,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
     const uint32_t wpix = ww * wh;                          // 0: no window for this batch
     const uint32_t W = (uint32_t)a.p.width;
+    const float inv_ww = 1.0f / (float)max(ww, 1u);
     // colour pass layout of the same 36 KiB: sums in the framebuffer's own packed format + the depth to test against
     unsigned long long *const s_rg = s_win, *const s_ba = s_win + WIN_PIXELS_HQS;
     uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * WIN_PIXELS_HQS);
@@ -434,7 +446,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #pragma unroll
         for (int k = 0; k < (WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE; ++k) {
             const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
-            const uint32_t y = i / max(ww, 1u), x = i - y * ww;
+            uint32_t y, x;
+            window_row_col(i, ww, inv_ww, y, x);
             v[k] = i < wpix ? a.f.fb[(size_t)(wy0 + y) * W + wx0 + x] : 0ull;
         }
 #pragma unroll
@@ -706,7 +719,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     if (wpix) {
         __syncthreads();
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
-            const uint32_t y = i / ww, x = i - y * ww;
+            uint32_t y, x;
+            window_row_col(i, ww, inv_ww, y, x);
             const size_t gp = (size_t)(wy0 + y) * W + wx0 + x;
             if (MODE == MODE_HQS_COLOR) {
                 const unsigned long long vba = s_ba[i];
@@ -839,8 +853,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
     const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
     const uint32_t wpix = ww * wh;
     const uint32_t W = (uint32_t)a.p.width;
+    const float inv_ww = 1.0f / (float)max(ww, 1u);
     for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
-        const uint32_t y = i / ww, x = i - y * ww;
+        uint32_t y, x;
+        window_row_col(i, ww, inv_ww, y, x);
         s_win[i] = a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
     }
     const pcr_xyz_batch g = a.s.batches[b];
@@ -917,7 +933,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
     if (wpix) {
         __syncthreads();
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
-            const uint32_t y = i / ww, x = i - y * ww;
+            uint32_t y, x;
+            window_row_col(i, ww, inv_ww, y, x);
             const unsigned long long v = s_win[i];
             unsigned long long *gp = (unsigned long long *)&a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
             if (v < *gp) atomicMin(gp, v);
