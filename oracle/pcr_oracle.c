@@ -221,6 +221,87 @@ static void decode_cluster(const pcr_oracle_stream *s, int64_t batch, int cluste
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The lane-major form the HIP path uses (k_transcode / k_render), restated on the CPU so that the
+ * equivalence it rests on is checked without a GPU: (1) walk a cluster in lockstep exactly as above and write down, per
+ * chain, the words it receives; (2) decode one chain from its own word sequence alone, as a plain bit stream.
+ * tests/test_oracle_format.py asserts (2) == pcr_oracle_decode_batch for every chain, tail garbage included.
+ * ---------------------------------------------------------------------------------------------- */
+int pcr_oracle_lane_words(const pcr_oracle_stream *s, int64_t batch, int rows, uint32_t *out, int32_t *counts)
+{
+    const pcr_gpu_batch *b = &s->batches[batch];
+    const int32_t *tl = s->dt_cwlen + b->decoder_table_offset;
+    const int max_cw = (int)b->max_cw_len;
+    const uint32_t mask = ((1u << max_cw) - 1u) << (32 - max_cw);
+    for (int cluster = 0; cluster < 32; ++cluster) {
+        int64_t enc_ptr = b->encoding_batch_offset;
+        if (cluster >= 1) enc_ptr += s->cluster_sizes[batch * 32 + cluster - 1];
+        uint32_t cur[32], nxt[32];
+        int cur_bits[32], n[32];
+        for (int l = 0; l < 32; ++l) {
+            const int chain = cluster * 32 + l;
+            cur[l] = enc_read(s, enc_ptr + l);
+            nxt[l] = enc_read(s, enc_ptr + 32 + l);
+            cur_bits[l] = 32;
+            if (rows < 2) return -1;
+            out[0 * 1024 + chain] = cur[l];
+            out[1 * 1024 + chain] = nxt[l];
+            n[l] = 2;
+        }
+        int64_t already_read = 64;
+        for (int k = 0; k < 64 * 3; ++k) {
+            uint32_t warp_mask = 0;
+            for (int l = 0; l < 32; ++l) {
+                uint32_t L = cur_bits[l] == 32 ? cur[l] : (cur[l] << (32 - cur_bits[l]));
+                uint32_t R = cur_bits[l] == 32 ? 0u : (nxt[l] >> cur_bits[l]);
+                uint32_t key = ((L | R) & mask) >> (32 - max_cw);
+                cur_bits[l] -= abs((signed char)tl[key]);
+                if (cur_bits[l] <= 0) warp_mask |= 1u << l;
+            }
+            int offset = 0;
+            for (int l = 0; l < 32; ++l) {
+                if (!(warp_mask & (1u << l))) continue;
+                cur[l] = nxt[l];
+                nxt[l] = enc_read(s, enc_ptr + already_read + offset);
+                cur_bits[l] += 32;
+                ++offset;
+                if (n[l] >= rows) return -1;
+                out[(size_t)n[l] * 1024 + cluster * 32 + l] = nxt[l];
+                ++n[l];
+            }
+            already_read += offset;
+        }
+        for (int l = 0; l < 32; ++l) counts[cluster * 32 + l] = n[l];
+    }
+    return 0;
+}
+
+void pcr_oracle_decode_chain_from_lane_words(const pcr_oracle_stream *s, int64_t batch, int chain, const uint32_t *words,
+                                             int num_words, int npr, int32_t *out_xyz)
+{
+    const pcr_gpu_batch *b = &s->batches[batch];
+    const int32_t *tv = s->dt_values + b->decoder_table_offset;
+    const int32_t *tl = s->dt_cwlen + b->decoder_table_offset;
+    int64_t sep_ptr = b->separate_batch_offset + (chain ? s->separate_sizes[batch * 1024 + chain - 1] : 0);
+    const int32_t *sv = s->start_values + ((int64_t)batch * 1024 + chain) * 3;
+    int32_t prev[3] = { sv[0], sv[1], sv[2] };
+    int64_t pos = 0;                                   /* bits consumed of the chain's own stream */
+    for (int i = 0; i < npr; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            /* the 12 bits at `pos` of the concatenated words (words[r * 1024] is the chain's r-th word) */
+            uint64_t w = 0;
+            const int64_t r = pos >> 5;
+            for (int k = 0; k < 2; ++k) w = (w << 32) | (r + k < num_words ? words[(size_t)(r + k) * 1024] : 0u);
+            const uint32_t key = (uint32_t)(w >> (64 - 12 - (pos & 31))) & 0xFFFu;
+            const int cw = (signed char)tl[key];
+            const int32_t d = cw > 0 ? tv[key] : sep_read(s, sep_ptr++);
+            pos += abs(cw);
+            prev[j] = (int32_t)((uint32_t)prev[j] + (uint32_t)d);
+        }
+        out_xyz[i * 3 + 0] = prev[0]; out_xyz[i * 3 + 1] = prev[1]; out_xyz[i * 3 + 2] = prev[2];
+    }
+}
+
 static void sink_store(void *ctx, int chain, int i, int32_t x, int32_t y, int32_t z)
 {
     int32_t *o = (int32_t *)ctx + ((size_t)chain * 64 + i) * 3;

@@ -87,6 +87,14 @@ int pcr_oracle_las_level(const pcr_xyz_batch *b, const pcr_render_params *p);
 void pcr_oracle_resolve_las(const pcr_render_params *p, const uint64_t *fb, const uint32_t *rgba_points,
                             uint32_t *rgba);
 
+/* Lane-major restatement (what k_transcode / k_render do on the GPU), for the CPU equivalence test:
+ * pcr_oracle_lane_words walks batch `batch` in lockstep and stores the r-th word chain c receives at out[r * 1024 + c]
+ * (rows rows available; counts[c] = words received; returns -1 if rows is too small);
+ * pcr_oracle_decode_chain_from_lane_words decodes npr points of one chain from `words` = &out[chain] alone. */
+int pcr_oracle_lane_words(const pcr_oracle_stream *s, int64_t batch, int rows, uint32_t *out, int32_t *counts);
+void pcr_oracle_decode_chain_from_lane_words(const pcr_oracle_stream *s, int64_t batch, int chain, const uint32_t *words,
+                                             int num_words, int npr, int32_t *out_xyz);
+
 /* Per-chain scalar table decoder (include/huffman.h:433-477), used to pin table semantics. */
 void pcr_oracle_decode_chain(const uint32_t *words, int64_t num_words, const int32_t *separate,
                              const int32_t *dt_values, const int32_t *dt_cwlen,

@@ -61,6 +61,9 @@ def lib() -> C.CDLL:
         L.pcr_oracle_render_las.restype = None
         L.pcr_oracle_resolve_las.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]
         L.pcr_oracle_resolve_las.restype = None
+        L.pcr_oracle_lane_words.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.pcr_oracle_decode_chain_from_lane_words.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.pcr_oracle_decode_chain_from_lane_words.restype = None
         _lib = L
     return _lib
 
@@ -106,6 +109,19 @@ class OracleFile:
     def decode_batch(self, b: int, npr: int = 64) -> np.ndarray:
         out = np.zeros((1024, 64, 3), np.int32)
         lib().pcr_oracle_decode_batch(self.stream, b, npr, out.ctypes.data)
+        return out
+
+    def lane_words(self, b: int, rows: int = 80):
+        """(words[rows, 1024], counts[1024]) of the lockstep walk: the lane-major form the HIP path decodes from."""
+        out = np.zeros((rows, 1024), np.uint32)
+        counts = np.zeros(1024, np.int32)
+        rc = lib().pcr_oracle_lane_words(self.stream, b, rows, out.ctypes.data, counts.ctypes.data)
+        assert rc == 0, "more words per chain than rows"
+        return out, counts
+
+    def decode_chain_from_lane_words(self, b: int, chain: int, words: np.ndarray, count: int, npr: int = 64) -> np.ndarray:
+        out = np.zeros((npr, 3), np.int32)
+        lib().pcr_oracle_decode_chain_from_lane_words(self.stream, b, chain, words[:, chain:].ctypes.data, count, npr, out.ctypes.data)
         return out
 
     def batch_lod(self, b: int, p: RenderParams, variant: int = MEM_ITER):

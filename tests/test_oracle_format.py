@@ -118,6 +118,31 @@ def test_pad_tails_variant_decodes_every_point_exactly(case):
     assert st_fixed["separate_bytes"] == st_plain["separate_bytes"] and st_fixed["escaped_symbols"] == st_plain["escaped_symbols"]
 
 
+@pytest.mark.parametrize("case", ["mostly_padding", "surface", "escape_heavy"])
+def test_lane_major_decode_equals_the_lockstep_decode(case):
+    """The invariant behind k_transcode / k_render, on the CPU: write down the words every chain receives
+    in the reference's lockstep walk, then decode each chain from its own sequence alone — same points, garbage tails
+    included, for the full decode and for level-of-detail prefixes; a chain never receives more than 74 words."""
+    if case == "mostly_padding":
+        image, _ = scenes.synth_stream(10_000)
+    elif case == "surface":
+        image, _ = scenes.synth_stream(200_000)
+    else:
+        x, y, z, c, las = scenes.random_points(65536, seed=9)
+        image, _ = P.encode_points(x, y, z, c, las, morton_sort=True, nthreads=2)
+    of = oracle.OracleFile(image.view())
+    b = of.num_batches - 1                                   # the last batch over-reads into the zero pad
+    words, counts = of.lane_words(b)
+    assert 2 <= counts.min() and counts.max() <= 74
+    full = of.decode_batch(b, 64)
+    part = of.decode_batch(b, 20)
+    for chain in list(range(0, 1024, 37)) + [31, 32, 1023]:
+        got = of.decode_chain_from_lane_words(b, chain, words, int(counts[chain]))
+        assert np.array_equal(got, full[chain]), f"chain {chain}"
+        got20 = of.decode_chain_from_lane_words(b, chain, words, int(counts[chain]), npr=20)
+        assert np.array_equal(got20, part[chain, :20])
+
+
 def test_lod_truncation_is_a_prefix_of_the_full_decode():
     image, _ = scenes.synth_stream(200_000)
     of = oracle.OracleFile(image.view())
