@@ -137,7 +137,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the first frame also pays for k_transcode (once per loaded batch: lane-major word order, packed table)
+    # first frame reported separately (one-time costs: code object upload, first launches); the lane-major transcode
+    # itself is part of loading (pcr_upload_batches) and inside load_s
     fence()
     t0 = time.perf_counter()
     step()

@@ -139,19 +139,42 @@ int check_params(pcr_ctx *c, const pcr_render_params *p)
     return PCR_OK;
 }
 
+StreamView make_stream_view(pcr_ctx *c)
+{
+    StreamView s;
+    s.batches = c->d_batches; s.start_values = c->d_start; s.encoded = c->d_encoded;
+    s.separate = c->d_separate; s.separate_sizes = c->d_sep_sizes; s.table_values = c->d_table_values;
+    s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors;
+    s.lane_words = c->d_lane_words; s.batch_flags = c->d_batch_flags; s.packed_table = c->d_packed_table;
+    s.encoded_words = c->enc_words; s.separate_words = c->sep_words;
+    s.num_batches = c->batches_loaded; s.batch_index_base = c->batch_index_base;
+    return s;
+}
+
 RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
 {
     RenderArgs a;
     a.p = *p;
-    a.s.batches = c->d_batches; a.s.start_values = c->d_start; a.s.encoded = c->d_encoded;
-    a.s.separate = c->d_separate; a.s.separate_sizes = c->d_sep_sizes; a.s.table_values = c->d_table_values;
-    a.s.table_lens = c->d_table_lens; a.s.cluster_sizes = c->d_cluster_sizes; a.s.colors = c->d_colors;
-    a.s.lane_words = c->d_lane_words; a.s.batch_flags = c->d_batch_flags; a.s.packed_table = c->d_packed_table;
-    a.s.encoded_words = c->enc_words; a.s.separate_words = c->sep_words;
-    a.s.num_batches = c->batches_loaded; a.s.batch_index_base = c->batch_index_base;
+    a.s = make_stream_view(c);
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
     a.lod = c->d_lod; a.win = c->d_win; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
     return a;
+}
+
+// Lane-major word sequences + packed tables (k_transcode) for every loaded batch that does not have them yet. A batch is
+// final once the batch behind it is loaded (its chains' tail over-reads, SURVEY B.4, reach into those words) or the
+// stream is complete; the last batch of an incomplete stream is walked provisionally (`include_provisional`, render
+// time only) and walked again when more data arrives. Part of loading: pcr_upload_batches calls this for what it can.
+void enqueue_transcode(pcr_ctx *c, bool include_provisional)
+{
+    const int64_t loaded = c->batches_loaded;
+    const int64_t final_end = loaded == c->hdr.num_batches ? loaded : loaded - 1;
+    const int64_t end = include_provisional ? loaded : final_end;
+    if (end > c->transcoded) {
+        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(end - c->transcoded)), dim3(PCR_WORKGROUP_SIZE), 0, c->stream,
+                           make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, (int)c->transcoded);
+        c->transcoded = std::max(c->transcoded, final_end);
+    }
 }
 
 template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
@@ -162,14 +185,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
     a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
-    if (c->transcoded < nB) {
-        // Newly loaded batches get their lane-major word sequences once. The last batch loaded before this call is
-        // redone with them: its chains' tail over-reads reach into the words that follow it, which were
-        // the zero pad until now. The very last batch stays provisional for the same reason until the stream is complete.
-        const int64_t first = c->transcoded;
-        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(nB - first)), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a.s, c->d_lane_words, c->d_batch_flags, c->d_packed_table, (int)first);
-        c->transcoded = nB == c->hdr.num_batches ? nB : nB - 1;
-    }
+    enqueue_transcode(c, true);      // normally only the provisional last batch of a stream that is still loading
     c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
     hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
@@ -422,6 +438,8 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     // stream order before any later render call
     c->enc_ptr = enc_ptr; c->sep_ptr = sep_ptr;
     c->batches_loaded += count; c->points_loaded += count * PCR_POINTS_PER_BATCH;   // HuffmanLasLoader.cpp:294-295
+    enqueue_transcode(c, false);     // this context's HBM layout of the stream is part of loading it
+    HIP_TRY(c, hipGetLastError());
     return PCR_OK;
 }
 
