@@ -59,7 +59,9 @@ int     pcr_upload_batch(pcr_ctx *ctx, int64_t batch_index, const void *blob, si
 /* A whole loader task at once (HuffmanLasData::process hands over <= 100 records, HuffmanLasLoader.cpp:301-313):
  * records first_index .. first_index+count-1, validated up front (nothing is uploaded if one is malformed), packed
  * into pinned staging memory and moved with nine large asynchronous copies. The records may be released on return;
- * the copies complete in stream order before any later render call. */
+ * the copies complete in stream order before any later render call. Behind the copies the context also writes its own
+ * HBM layout of the new batches (lane-major word order, packed decoder tables: DESIGN.md 4) — loading work, once per
+ * batch, nothing decoded. */
 int     pcr_upload_batches(pcr_ctx *ctx, int64_t first_index, int64_t count, const void *const *blobs, const size_t *sizes);
 int     pcr_upload_tail(pcr_ctx *ctx, const uint32_t *encoded_words, size_t n_encoded,
                         const int32_t *separate_words, size_t n_separate);
