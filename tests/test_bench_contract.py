@@ -1,0 +1,43 @@
+"""The bench line contract, checked on the committed record of the last GPU run (no GPU needed): every key the driver
+and the judge read is present with the right type, and the derived numbers are consistent with each other."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORD = os.path.join(ROOT, "profiles", "r01_v25_bench_basic.json")
+
+
+@pytest.fixture(scope="module")
+def line():
+    with open(RECORD) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_required_keys_and_types(line):
+    for key, typ in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert key in line and isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["data"] == "synthetic"
+    assert isinstance(line["config"]["workload"], str) and "model" not in line["config"]
+    r = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    c = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_numbers_are_consistent(line):
+    pts = line["config"]["points_per_step"]
+    assert abs(line["value"] - pts / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
+    r = line["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    assert line["parity_full_size"] is True
+    assert r["kernel_ms"] <= line["ms_per_step"]
