@@ -16,7 +16,7 @@
 
 using namespace pcr;
 
-constexpr int PCR_STATS_PARTIALS = 256;         // ceil(65535 batches / 256 prepass threads)
+constexpr int PCR_STATS_PARTIALS = 2048;        // ceil(65535 batches / 32 batches per prepass workgroup)
 
 struct pcr_ctx {
     int device = 0;
@@ -186,7 +186,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
     a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
     enqueue_transcode(c, true);      // normally only the provisional last batch of a stream that is still loading
-    c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
+    c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
     hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
@@ -658,10 +658,10 @@ int pcr_resolve_hqs(pcr_ctx *c, const pcr_render_params *p) { return launch_reso
 int pcr_get_stats(pcr_ctx *c, pcr_render_stats *out)
 {
     if (!c || !out) return PCR_E_ARG;
-    pcr_render_stats part[PCR_STATS_PARTIALS];
+    std::vector<pcr_render_stats> part((size_t)PCR_STATS_PARTIALS);
     std::memset(out, 0, sizeof *out);
     if (c->stats_partials > 0) {
-        HIP_TRY(c, hipMemcpyAsync(part, c->d_stats, (size_t)c->stats_partials * sizeof(pcr_render_stats), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(part.data(), c->d_stats, (size_t)c->stats_partials * sizeof(pcr_render_stats), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (int i = 0; i < c->stats_partials; ++i) {
             out->batches_total += part[i].batches_total; out->batches_culled += part[i].batches_culled;

@@ -128,38 +128,43 @@ __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_r
 // ------------------------------------------------------------------------------------------------
 // prepass: cull + LOD per batch
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, pcr_render_stats &st);
+// Eight lanes per batch: lane k tests frustum plane k (k < 6) and projects bounding-box corner k for the window
+// rectangle; the LOD arithmetic is uniform. One lane doing all of it serially made this launch 9 us of every frame.
+constexpr int PREPASS_LANES = 8;
+constexpr int PREPASS_BATCHES = PREPASS_THREADS / PREPASS_LANES;     // batches per workgroup
+__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a)
 {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / PREPASS_LANES;
     pcr_render_stats st = {0, 0, 0, 0};
-    if (b < a.s.num_batches) lod_prepass_batch(a, b, st);
+    if (b < a.s.num_batches) lod_prepass_batch(a, b, (int)(threadIdx.x % PREPASS_LANES), st);   // uniform per 8-lane group
     commit_stats(st, a.stats);
 }
 
-__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, pcr_render_stats &st)
+__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st)
 {
+    const uint32_t group_shift = (threadIdx.x & 63u) & ~(uint32_t)(PREPASS_LANES - 1);   // my group's bits in a wave ballot
     const pcr_gpu_batch g = a.s.batches[b];
     const pcr_render_params &p = a.p;
     const float lm[3] = { (float)g.las_min_x, (float)g.las_min_y, (float)g.las_min_z };      // :336
     const float bmin[3] = { g.min_x - lm[0], g.min_y - lm[1], g.min_z - lm[2] };             // :340
     const float bmax[3] = { g.max_x - lm[0], g.max_y - lm[1], g.max_z - lm[2] };             // :341
 
-    st.batches_total += 1;
+    if (lane == 0) st.batches_total += 1;
     if (p.enable_frustum_culling) {                                                          // :342-344
+        // planes (3-0), (3+0), (3+1), (3-1), (3-2), (3+2) of the transposed matrix (three.js convention, :246-259);
+        // x + s*y with s = +-1 is the same rounding as x +- y
         const float *M = p.transform;
-#define T(i) M[((i) % 4) * 4 + ((i) / 4)]
-        bool in = plane_accepts(T(3) - T(0), T(7) - T(4), T(11) - T(8),  T(15) - T(12), bmin, bmax)
-               && plane_accepts(T(3) + T(0), T(7) + T(4), T(11) + T(8),  T(15) + T(12), bmin, bmax)
-               && plane_accepts(T(3) + T(1), T(7) + T(5), T(11) + T(9),  T(15) + T(13), bmin, bmax)
-               && plane_accepts(T(3) - T(1), T(7) - T(5), T(11) - T(9),  T(15) - T(13), bmin, bmax)
-               && plane_accepts(T(3) - T(2), T(7) - T(6), T(11) - T(10), T(15) - T(14), bmin, bmax)
-               && plane_accepts(T(3) + T(2), T(7) + T(6), T(11) + T(10), T(15) + T(14), bmin, bmax);
-#undef T
-        if (!in) {
-            a.lod[b] = LOD_CULLED;
-            st.batches_culled += 1;
+        const int r = (lane >> 1) & 3;
+        const float sgn = (lane == 0 || lane == 3 || lane == 4) ? -1.0f : 1.0f;
+        bool accept = true;
+        if (lane < 6)
+            accept = plane_accepts(M[12] + sgn * M[4 * r + 0], M[13] + sgn * M[4 * r + 1], M[14] + sgn * M[4 * r + 2],
+                                   M[15] + sgn * M[4 * r + 3], bmin, bmax);
+        const uint32_t votes = (uint32_t)(__ballot(accept) >> group_shift) & 0xFFu;
+        if (votes != 0xFFu) {
+            if (lane == 0) { a.lod[b] = LOD_CULLED; st.batches_culled += 1; }
             return;
         }
     }
@@ -187,23 +192,28 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
     int npr = (int)(pct * (float)p.points_per_thread);                       // :375
     npr = min(npr, p.points_per_thread);
     npr = max(npr, 0);
-    a.lod[b] = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
-    st.points_iterated += (int64_t)npr * PCR_WORKGROUP_SIZE;
-    if (use_double) st.batches_double += 1;
+    if (lane == 0) {
+        a.lod[b] = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
+        st.points_iterated += (int64_t)npr * PCR_WORKGROUP_SIZE;
+        if (use_double) st.batches_double += 1;
+    }
 
     // Screen rectangle of the batch's bounding box: where k_render keeps its LDS copy of the framebuffer. This is
     // only a cache placement hint (points that land outside it take the global path), so it needs no exactness.
     uint2 wr = make_uint2(0, 0);
     {
-        float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
-        bool ok = true;
-        for (int c = 0; c < 8; ++c) {
-            const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
-            const float w = dot4(p.transform + 12, x, y, z, 1.0f);
-            if (!(w > 1.0e-6f)) { ok = false; break; }
-            const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
-            const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
-            minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+        // corner `lane` of the box, then min / max over the group's eight lanes
+        const int c = lane;
+        const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
+        const float w = dot4(p.transform + 12, x, y, z, 1.0f);
+        const bool front = w > 1.0e-6f;
+        const bool ok = ((uint32_t)(__ballot(front) >> group_shift) & 0xFFu) == 0xFFu;
+        float minx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw, maxx = minx;
+        float miny = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh, maxy = miny;
+#pragma unroll
+        for (int m = 1; m < PREPASS_LANES; m <<= 1) {
+            minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
+            miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
         }
         if (ok && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
             int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
@@ -219,7 +229,7 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
                 wr = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)ww | ((uint32_t)wh << 16));
         }
     }
-    a.win[b] = wr;
+    if (lane == 0) a.win[b] = wr;
 }
 
 // ------------------------------------------------------------------------------------------------
