@@ -45,6 +45,8 @@ def parse_args():
                     help="multi-GPU exchange: min-reduce the partial framebuffers to rank 0 (the display rank) or all-reduce them")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="keep the per-launch kernel events out of the timed steps (A/B of their overhead)")
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = automatic (bounded)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for generation / CPU baseline")
     return ap.parse_args()
@@ -147,11 +149,18 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step()
     fence()
+    launches_per_step = 1 if args.method == "basic" else 2
+    ctx.kernel_timing(0 if args.no_kernel_events else max(1, args.steps * launches_per_step // 64) | 1)   # odd: samples both HQS passes
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if args.no_kernel_events:       # A/B of the event overhead: time the kernel in a second, untimed pass instead
+        ctx.kernel_timing(True)
+        for _ in range(min(args.steps, 64)):
+            step()
+        fence()
 
     st = ctx.stats()            # counters of the last render launch (per rank)
     pts = torch.tensor([st["points_iterated"]], dtype=torch.float64, device=dev)
@@ -164,17 +173,11 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = points_per_step / (elapsed / args.steps) / 1e6
 
-    # ---- dominant kernel alone, HIP events on the stream it is launched on -------------------------------
-    kern = ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth
-    kreps = max(3, min(args.steps, 10))
-    ctx.clear(); kern(p); ctx.synchronize()
-    kms = []
-    for _ in range(kreps):
-        ctx.clear()
-        ctx.timing_begin()
-        kern(p)                 # = k_lod_prepass (1526 threads) + k_render<MODE> (1526 workgroups)
-        kms.append(ctx.timing_end())
-    kernel_ms = sum(kms) / len(kms)
+    # ---- dominant kernel: per-launch HIP event pairs recorded inside pcr_render_* on the context's stream, around
+    # k_render only, during the timed steps above (pcr_kernel_timing_*; a stride keeps it to <=64 pairs spread over the
+    # whole timed region, since an event pair costs ~5 us of stream time) ---------------------------------------------
+    kernel_ms, kernel_launches = ctx.kernel_timing_read()
+    ctx.kernel_timing(False)
     alg_bytes = ctx.algorithmic_bytes                      # decode-pass bytes of this rank's shard (SURVEY 8d B_dec * points)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     traffic = None
@@ -188,8 +191,8 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "k_render<%s>" % ("basic" if args.method == "basic" else "hqs_depth"),
-                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": alg_bytes,
+                "kernel": "k_render<%s>" % ("basic" if args.method == "basic" else "hqs_depth+hqs_color"),
+                "kernel_ms": round(kernel_ms, 4), "kernel_launches_timed": kernel_launches, "algorithmic_bytes": alg_bytes,
                 "bytes_per_point": round(alg_bytes / max(1, st["points_iterated"]), 4)}
 
     # ---- CPU baseline + full-size parity check (rank 0, N == 1 only) ----------------------------------------
@@ -210,7 +213,7 @@ def main():
                         "sample": "%d of %d batches (%d points) of the same stream and camera, oracle/pcr_oracle.c, %.1f s wall"
                                   % (sample, nb, ost["points_iterated"], cpu_s)}
         if sample == nb:        # same inputs end to end: compare the whole framebuffer, bit for bit
-            ctx.clear(); kern(p)
+            ctx.clear(); (ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth)(p)
             parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb))
 
     if rank == 0:

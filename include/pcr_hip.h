@@ -143,6 +143,12 @@ int   pcr_flip_sign(pcr_ctx *ctx);
  * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
 int pcr_timing_begin(pcr_ctx *ctx);
 int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
+/* Per-launch duration of the dominant kernel: with every = n > 0, every n-th pcr_render_* call brackets its
+ * decode+rasterize kernel (not the prepass) with a HIP event pair on the stream it is launched on (an event pair costs
+ * ~5 us of stream time, hence the stride); every = 0 switches it off. pcr_kernel_timing_read synchronises and returns
+ * the average over the most recent bracketed launches (at most 64) since enabling, and how many those were. */
+int pcr_kernel_timing_enable(pcr_ctx *ctx, int every);
+int pcr_kernel_timing_read(pcr_ctx *ctx, float *avg_ms, int *launches);
 
 /* Algorithmic HBM bytes of one render launch over the loaded stream, SURVEY 8d's B_dec x points: every byte of the
  * compressed representation once (encoded + separate + cluster prefix + per batch 160 + 12 288 + 4 096 + 32 768). */

@@ -72,6 +72,13 @@ struct pcr_ctx {
     bool accum_dirty = true;    // RG/BA hold something other than zeros (only the HQS colour pass writes them)
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // per-launch timing of the dominant kernel (pcr_kernel_timing_*): event pairs around k_render / k_las_render only
+    static constexpr int KT_PAIRS = 64;
+    hipEvent_t kt_begin[KT_PAIRS] = {}, kt_end[KT_PAIRS] = {};
+    int kt_every = 0;                           // 0 = off, n = bracket every n-th launch
+    int64_t kt_launches = 0;                    // launches since enable
+    int64_t kt_samples = 0;                     // bracketed launches since enable (only the last KT_PAIRS are kept)
+    bool kt_sample_now() const { return kt_every > 0 && kt_launches % kt_every == 0; }
 };
 
 namespace {
@@ -188,7 +195,12 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     enqueue_transcode(c, true);      // normally only the provisional last batch of a stream that is still loading
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
+    const bool timed = c->kt_sample_now();
+    const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
+    if (timed) HIP_TRY(c, hipEventRecord(c->kt_begin[slot], c->stream));
     hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    if (timed) { HIP_TRY(c, hipEventRecord(c->kt_end[slot], c->stream)); ++c->kt_samples; }
+    if (c->kt_every > 0) ++c->kt_launches;
     HIP_TRY(c, hipGetLastError());
     return PCR_OK;
 }
@@ -241,6 +253,10 @@ void pcr_destroy(pcr_ctx *c)
     for (int i = 0; i < 2; ++i) {
         if (c->arena[i]) (void)hipHostFree(c->arena[i]);
         if (c->arena_done[i]) (void)hipEventDestroy(c->arena_done[i]);
+    }
+    for (int i = 0; i < pcr_ctx::KT_PAIRS; ++i) {
+        if (c->kt_begin[i]) (void)hipEventDestroy(c->kt_begin[i]);
+        if (c->kt_end[i]) (void)hipEventDestroy(c->kt_end[i]);
     }
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -610,7 +626,12 @@ int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
     a.level = c->d_las_level; a.win = c->d_las_win; a.stats = c->d_stats; a.win_capacity = WIN_PIXELS;
     c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
     hipLaunchKernelGGL(k_las_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
+    const bool timed = c->kt_sample_now();
+    const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
+    if (timed) HIP_TRY(c, hipEventRecord(c->kt_begin[slot], c->stream));
     hipLaunchKernelGGL(k_las_render, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    if (timed) { HIP_TRY(c, hipEventRecord(c->kt_end[slot], c->stream)); ++c->kt_samples; }
+    if (c->kt_every > 0) ++c->kt_launches;
     HIP_TRY(c, hipGetLastError());
     return PCR_OK;
 }
@@ -759,6 +780,39 @@ int pcr_timing_end(pcr_ctx *c, float *ms)
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->ev_end));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
+    return PCR_OK;
+}
+
+int pcr_kernel_timing_enable(pcr_ctx *c, int every)
+{
+    if (!c || every < 0) return PCR_E_ARG;
+    const int on = every;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (on && !c->kt_begin[0])
+        for (int i = 0; i < pcr_ctx::KT_PAIRS; ++i) {
+            HIP_TRY(c, hipEventCreate(&c->kt_begin[i]));
+            HIP_TRY(c, hipEventCreate(&c->kt_end[i]));
+        }
+    c->kt_every = every;
+    c->kt_launches = 0;
+    c->kt_samples = 0;
+    return PCR_OK;
+}
+
+int pcr_kernel_timing_read(pcr_ctx *c, float *avg_ms, int *launches)
+{
+    if (!c || !avg_ms || !launches) return PCR_E_ARG;
+    *avg_ms = 0.0f; *launches = 0;
+    const int n = (int)std::min<int64_t>(c->kt_samples, pcr_ctx::KT_PAIRS);
+    if (n == 0) return PCR_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->kt_begin[i], c->kt_end[i]));
+        sum += ms;
+    }
+    *avg_ms = (float)(sum / n); *launches = n;
     return PCR_OK;
 }
 

@@ -414,6 +414,16 @@ class Context:
     def flip_sign(self):
         self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
 
+    def kernel_timing(self, every: int) -> None:
+        """Bracket every `every`-th decode+rasterize launch with HIP events (0/False = off)."""
+        self._chk(self.lib.pcr_kernel_timing_enable(self.h, int(every)), "pcr_kernel_timing_enable")
+
+    def kernel_timing_read(self) -> tuple[float, int]:
+        """(average ms of the decode+rasterize kernel over the most recent launches, how many)."""
+        ms, n = C.c_float(), C.c_int()
+        self._chk(self.lib.pcr_kernel_timing_read(self.h, C.byref(ms), C.byref(n)), "pcr_kernel_timing_read")
+        return float(ms.value), int(n.value)
+
     def timing_begin(self):
         self._chk(self.lib.pcr_timing_begin(self.h), "pcr_timing_begin")
 

@@ -233,3 +233,27 @@ def test_progressive_loading_frames_equal_the_truncated_stream(renderer):
     finally:
         P.Debug.LOD, P.Debug.frustumCullingEnabled = 0.1, True
         las.unload(renderer)
+
+
+def test_kernel_timing_counts_render_launches_only(renderer, stream200k):
+    """pcr_kernel_timing_*: one event pair per decode+rasterize launch, none for clear/resolve, off by default."""
+    nb, of = stream200k
+    _load(renderer, nb)
+    ctx = renderer.ctx
+    renderer.set_camera(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0))
+    p = renderer.render_params()
+    ctx.clear(); ctx.render_basic(p)
+    assert ctx.kernel_timing_read() == (0.0, 0)
+    ctx.kernel_timing(True)
+    for _ in range(5):
+        ctx.clear(); ctx.render_basic(p); ctx.resolve_basic(p)
+    ms, n = ctx.kernel_timing_read()
+    assert n == 5 and 0.0 < ms < 50.0
+    for _ in range(70):
+        ctx.clear(); ctx.render_basic(p)
+    ms, n = ctx.kernel_timing_read()
+    assert n == 64 and 0.0 < ms < 50.0
+    ctx.kernel_timing(False)
+    ctx.render_basic(p)
+    assert ctx.kernel_timing_read() == (0.0, 0)
+    _check_basic(ctx, of, p)

@@ -75,19 +75,15 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
+    ctx.kernel_timing(True)         # event pair around k_las_render of each timed step (pcr_kernel_timing_*)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
-    kms = []
-    for _ in range(10):
-        ctx.clear()
-        ctx.timing_begin()
-        ctx.render_las(p)
-        kms.append(ctx.timing_end())
-    kernel_ms = sum(kms) / len(kms)
+    kernel_ms, _ = ctx.kernel_timing_read()
+    ctx.kernel_timing(False)
     alg = ctx.las_algorithmic_bytes
     achieved = alg / (kernel_ms * 1e-3) / 1e9
     parity = None

@@ -7,8 +7,10 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+BENCH_FULL="$PWD/bench.py --no-cpu-baseline $*"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $BENCH > "$OUT/stats.log" 2>&1 || { tail -20 "$OUT/stats.log"; exit 1; }
+# the stats pass runs the bench at its default length so that its k_render average can be set beside roofline.kernel_ms
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $BENCH_FULL > "$OUT/stats.log" 2>&1 || { tail -20 "$OUT/stats.log"; exit 1; }
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
