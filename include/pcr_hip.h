@@ -141,6 +141,17 @@ int   pcr_flip_sign(pcr_ctx *ctx);
 /* ---- measurement ---------------------------------------------------------------------------------
  * HIP events on the context's stream: begin/end bracket any sequence of enqueued calls;
  * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
+/* Asynchronous loader. Off (default): pcr_upload_batches enqueues its copies and the transcode on the
+ * context's stream, in order with the frames, and a frame draws every batch handed over so far, as the reference's
+ * process() does (HuffmanLasLoader.cpp:301-313). On: they run on a loader stream of the context's own, the call
+ * returns once the records are packed into a pinned arena, and a frame draws the batches whose loader task is known to
+ * have completed (never the last arrived batch of an incomplete stream: its chains' tail over-reads reach into the
+ * next batch's words), so frames do not wait for PCIe. pcr_batches_resident: how many batches the next frame draws at
+ * least (= pcr_batches_loaded when the mode is off). Switching synchronises. */
+int pcr_set_async_upload(pcr_ctx *ctx, int on);
+int64_t pcr_batches_resident(pcr_ctx *ctx);
+int64_t pcr_last_frame_batches(const pcr_ctx *ctx);   /* batches drawn by the last pcr_render_* call */
+
 int pcr_timing_begin(pcr_ctx *ctx);
 int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
 /* Per-launch duration of the dominant kernel: with every = n > 0, every n-th pcr_render_* call brackets its

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -54,6 +55,16 @@ struct pcr_ctx {
     hipEvent_t arena_done[2] = {nullptr, nullptr};
     bool arena_busy[2] = {false, false};
     int arena_next = 0;
+    // asynchronous loader (pcr_set_async_upload): copies + transcode on a stream of their own; a render launch draws the
+    // batches whose loader task is known to have completed, so frames never wait for the PCIe copy
+    bool async_upload = false;
+    hipStream_t copy_stream = nullptr;
+    struct LoaderTask { hipEvent_t done; int64_t resident_after; };
+    std::deque<LoaderTask> loader_tasks;
+    std::vector<hipEvent_t> loader_events;      // recycled
+    int64_t batches_resident = 0;
+    int64_t last_frame_batches = 0;
+    int64_t visible_batches() const { return async_upload ? batches_resident : batches_loaded; }
 
     // resource of the 10-10-10 path (ComputeLasData)
     bool las_open = false;
@@ -102,8 +113,24 @@ int set_err(pcr_ctx *c, int code, const char *fmt, ...)
 
 template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
+// Async loader: retire the tasks whose event has fired (or, with wait, all of them).
+void poll_loader(pcr_ctx *c, bool wait)
+{
+    while (!c->loader_tasks.empty()) {
+        pcr_ctx::LoaderTask &t = c->loader_tasks.front();
+        if (wait) (void)hipEventSynchronize(t.done);
+        else if (hipEventQuery(t.done) != hipSuccess) break;
+        c->batches_resident = t.resident_after;
+        c->loader_events.push_back(t.done);
+        c->loader_tasks.pop_front();
+    }
+}
+
 void free_stream_buffers(pcr_ctx *c)
 {
+    poll_loader(c, true);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->batches_resident = 0;
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); c->transcoded = 0;
@@ -154,7 +181,7 @@ StreamView make_stream_view(pcr_ctx *c)
     s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors;
     s.lane_words = c->d_lane_words; s.batch_flags = c->d_batch_flags; s.packed_table = c->d_packed_table;
     s.encoded_words = c->enc_words; s.separate_words = c->sep_words;
-    s.num_batches = c->batches_loaded; s.batch_index_base = c->batch_index_base;
+    s.num_batches = c->visible_batches(); s.batch_index_base = c->batch_index_base;
     return s;
 }
 
@@ -172,13 +199,13 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
 // final once the batch behind it is loaded (its chains' tail over-reads, SURVEY B.4, reach into those words) or the
 // stream is complete; the last batch of an incomplete stream is walked provisionally (`include_provisional`, render
 // time only) and walked again when more data arrives. Part of loading: pcr_upload_batches calls this for what it can.
-void enqueue_transcode(pcr_ctx *c, bool include_provisional)
+void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
 {
     const int64_t loaded = c->batches_loaded;
     const int64_t final_end = loaded == c->hdr.num_batches ? loaded : loaded - 1;
     const int64_t end = include_provisional ? loaded : final_end;
     if (end > c->transcoded) {
-        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(end - c->transcoded)), dim3(PCR_WORKGROUP_SIZE), 0, c->stream,
+        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(end - c->transcoded)), dim3(PCR_WORKGROUP_SIZE), 0, st,
                            make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, (int)c->transcoded);
         c->transcoded = std::max(c->transcoded, final_end);
     }
@@ -188,11 +215,13 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
 {
     int rc = check_params(c, p);
     if (rc) return rc;
-    const int64_t nB = c->batches_loaded;            // "don't execute a workgroup until all points inside are loaded"
+    if (c->async_upload) poll_loader(c, false);
+    const int64_t nB = c->visible_batches();         // "don't execute a workgroup until all points inside are loaded"
+    c->last_frame_batches = nB;
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
     a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
-    enqueue_transcode(c, true);      // normally only the provisional last batch of a stream that is still loading
+    if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
     const bool timed = c->kt_sample_now();
@@ -260,6 +289,8 @@ void pcr_destroy(pcr_ctx *c)
     }
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    for (hipEvent_t e : c->loader_events) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -438,7 +469,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
 
     // ---- nine copies for the whole task ---------------------------------------------------------------------------
     const size_t b0 = (size_t)first_index;
-    hipStream_t st = c->stream;
+    hipStream_t st = c->async_upload ? c->copy_stream : c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->d_batches + b0, A + o_batches, nb * sizeof(pcr_gpu_batch), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_start + b0 * 3072, A + o_start, nb * 3072 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_sep_sizes + b0 * 1024, A + o_sepsz, nb * 1024 * 4, hipMemcpyHostToDevice, st));
@@ -454,8 +485,16 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     // stream order before any later render call
     c->enc_ptr = enc_ptr; c->sep_ptr = sep_ptr;
     c->batches_loaded += count; c->points_loaded += count * PCR_POINTS_PER_BATCH;   // HuffmanLasLoader.cpp:294-295
-    enqueue_transcode(c, false);     // this context's HBM layout of the stream is part of loading it
+    enqueue_transcode(c, false, st);    // this context's HBM layout of the stream is part of loading it
     HIP_TRY(c, hipGetLastError());
+    if (c->async_upload) {
+        // a batch becomes drawable with the task that brings the words behind it (its chains' tail over-reads)
+        hipEvent_t ev;
+        if (c->loader_events.empty()) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else { ev = c->loader_events.back(); c->loader_events.pop_back(); }
+        HIP_TRY(c, hipEventRecord(ev, st));
+        c->loader_tasks.push_back({ev, c->transcoded});
+    }
     return PCR_OK;
 }
 
@@ -468,10 +507,16 @@ int pcr_upload_tail(pcr_ctx *c, const uint32_t *enc, size_t n_enc, const int32_t
     if ((size_t)(c->enc_words - c->enc_ptr) < n_enc || (size_t)(c->sep_words - c->sep_ptr) < n_sep)
         return set_err(c, PCR_E_ARG, "tail does not fit behind the uploaded batches");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->async_upload) poll_loader(c, true);
     if (n_enc) HIP_TRY(c, hipMemcpyAsync(c->d_encoded + c->enc_ptr, enc, n_enc * 4, hipMemcpyHostToDevice, c->stream));
     if (n_sep) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, sep, n_sep * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->batches_loaded > 0 && c->transcoded >= c->batches_loaded) c->transcoded = c->batches_loaded - 1;   // its over-reads see these words
+    if (c->async_upload) {           // no render-time transcode in this mode: redo the last batch now
+        enqueue_transcode(c, true, c->stream);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->batches_resident = c->transcoded;
+    }
     return PCR_OK;
 }
 
@@ -485,6 +530,33 @@ int pcr_stream_unload(pcr_ctx *c)
 }
 
 int64_t pcr_batches_loaded(const pcr_ctx *c) { return c ? c->batches_loaded : 0; }
+
+int pcr_set_async_upload(pcr_ctx *c, int on)
+{
+    if (!c) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((on != 0) == c->async_upload) return PCR_OK;
+    if (on) {
+        if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));         // earlier loader work (zero fill, copies, transcode) is behind us
+        c->batches_resident = c->transcoded;                 // a provisional last batch is drawn again once its successor arrives
+        c->async_upload = true;
+    } else {
+        poll_loader(c, true);
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        c->async_upload = false;
+    }
+    return PCR_OK;
+}
+
+int64_t pcr_last_frame_batches(const pcr_ctx *c) { return c ? c->last_frame_batches : 0; }
+
+int64_t pcr_batches_resident(pcr_ctx *c)
+{
+    if (!c) return 0;
+    if (c->async_upload) poll_loader(c, false);
+    return c->visible_batches();
+}
 int64_t pcr_points_loaded(const pcr_ctx *c) { return c ? c->points_loaded : 0; }
 
 int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)

@@ -161,6 +161,8 @@ struct HuffmanLasData : Resource {
     int64_t numBatches = 0, numPoints = 0, encodedBytes = 0, separateBytes = 0, clusterBytes = 0;
     std::vector<int64_t> batch_data_sizes, batch_data_sizes_prefix;
     int64_t numBatchesLoaded = 0, numPointsLoaded = 0, offsetToBatchData = 0;
+    int64_t numBatchesResident = 0;     // what the next frame draws; lags numBatchesLoaded only with asyncUpload
+    bool asyncUpload = false;           // copies + transcode on the context's loader stream (pcr_set_async_upload)
 
     std::shared_ptr<LoaderTask> task;
     std::mutex mtx_state, mtx_tasks;
@@ -202,7 +204,8 @@ struct HuffmanLasData : Resource {
         }
         pcr_file_header hdr{numPoints, numBatches, encodedBytes, separateBytes, clusterBytes};
         renderer->check(pcr_stream_begin(renderer->ctx, &hdr, 0), "pcr_stream_begin");
-        numBatchesLoaded = numPointsLoaded = 0;
+        renderer->check(pcr_set_async_upload(renderer->ctx, asyncUpload ? 1 : 0), "pcr_set_async_upload");
+        numBatchesLoaded = numPointsLoaded = numBatchesResident = 0;
         reader = std::thread([this] {
             std::ifstream f(path, std::ios::binary);
             int64_t remaining = numBatches, read = 0;
@@ -260,6 +263,11 @@ struct HuffmanLasData : Resource {
     }
 
     bool fullyLoaded() const { return numBatchesLoaded == numBatches; }
+    bool fullyResident(Renderer *renderer)
+    {
+        numBatchesResident = pcr_batches_resident(renderer->ctx);
+        return numBatchesResident == numBatches;
+    }
 
 private:
     void stopReader()

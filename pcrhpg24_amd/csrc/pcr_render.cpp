@@ -4,6 +4,7 @@
 //   pcr_render <file.huffman> [--method huffman_mem_iter_cuda|huffman_hqs] [--size WxH]
 //   pcr_render <file.las>      --method loop_las_cuda                      [--size WxH]
 //              [--camera yaw pitch radius tx ty tz] [--lod 0.1] [--cull 0|1] [--frames N]
+//              [--async-load]   (.huffman: copies on the loader stream, frames draw what has arrived)
 //              [--dump-fb fb.u64] [--dump-rgba out.ppm] [--dump-depth depth.exr]   (depth: huffman_hqs only, huffman_hqs.h:217-237)
 // Prints one JSON line: batches, frames needed to load, ms of the last frame, FNV-1a of the u64 framebuffer.
 #include <chrono>
@@ -28,6 +29,7 @@ int main(int argc, char **argv)
     if (argc < 2) { std::fprintf(stderr, "usage: pcr_render <file.huffman> [options]\n"); return 2; }
     std::string path = argv[1], method = "huffman_mem_iter_cuda", dump_fb, dump_rgba, dump_depth;
     int w = 1920, h = 1080, frames = 0;
+    bool async_load = false;
     // src/main.cpp:192-218 default setting ("morrobay" overview)
     double cam[6] = {-0.15, -0.57, 3166.32, 2239.05, 1713.63, -202.02};
     for (int i = 2; i < argc; ++i) {
@@ -39,6 +41,7 @@ int main(int argc, char **argv)
         else if (a == "--lod") { need(1); Debug::LOD = (float)std::atof(argv[++i]); }
         else if (a == "--cull") { need(1); Debug::frustumCullingEnabled = std::atoi(argv[++i]) != 0; }
         else if (a == "--frames") { need(1); frames = std::atoi(argv[++i]); }
+        else if (a == "--async-load") { async_load = true; }
         else if (a == "--dump-fb") { need(1); dump_fb = argv[++i]; }
         else if (a == "--dump-rgba") { need(1); dump_rgba = argv[++i]; }
         else if (a == "--dump-depth") { need(1); dump_depth = argv[++i]; }
@@ -58,6 +61,7 @@ int main(int argc, char **argv)
             Runtime::addMethod(m0.get());
         } else {
             las_huffman = HuffmanLasData::create(path);                 // main.cpp:244
+            las_huffman->asyncUpload = async_load;
             m0 = std::make_unique<HuffmanMemIter>(&renderer, las_huffman);   // main.cpp:266-267
             m1 = std::make_unique<HuffmanHQS>(&renderer, las_huffman);
             Runtime::addMethod(m0.get());                               // main.cpp:272-273
@@ -77,7 +81,7 @@ int main(int argc, char **argv)
             renderer.check(pcr_synchronize(renderer.ctx), "pcr_synchronize");
             ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             ++n;
-            bool loaded = las_huffman ? las_huffman->fullyLoaded() : las_compute->fullyLoaded();
+            bool loaded = las_huffman ? las_huffman->fullyLoaded() && las_huffman->fullyResident(&renderer) : las_compute->fullyLoaded();
             if (frames > 0 ? n >= frames && loaded : loaded) break;
             if (n > 100000) throw std::runtime_error("loader made no progress");
         }

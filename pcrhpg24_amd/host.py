@@ -414,6 +414,18 @@ class Context:
     def flip_sign(self):
         self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
 
+    def set_async_upload(self, on: bool) -> None:
+        """Loader copies + transcode on the context's loader stream; frames draw what has arrived (pcr_hip.h)."""
+        self._chk(self.lib.pcr_set_async_upload(self.h, int(on)), "pcr_set_async_upload")
+
+    @property
+    def batches_resident(self) -> int:
+        return int(self.lib.pcr_batches_resident(self.h))
+
+    @property
+    def last_frame_batches(self) -> int:
+        return int(self.lib.pcr_last_frame_batches(self.h))
+
     def kernel_timing(self, every: int) -> None:
         """Bracket every `every`-th decode+rasterize launch with HIP events (0/False = off)."""
         self._chk(self.lib.pcr_kernel_timing_enable(self.h, int(every)), "pcr_kernel_timing_enable")

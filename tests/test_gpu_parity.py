@@ -257,3 +257,51 @@ def test_kernel_timing_counts_render_launches_only(renderer, stream200k):
     ctx.render_basic(p)
     assert ctx.kernel_timing_read() == (0.0, 0)
     _check_basic(ctx, of, p)
+
+
+def test_async_loader_frames_draw_what_has_arrived(renderer):
+    """pcr_set_async_upload: copies + transcode on the loader stream; a frame draws the first k batches
+    whose tasks have completed, never the newest batch of an incomplete stream, and equals the oracle's render of
+    batches [0, k) of the whole file; once everything is resident the frame is the whole file's."""
+    import time
+    nb, st = P.synth_encode(16_000_000, scenes.SEED, nthreads=8)            # 245 batches
+    hf = P.HuffmanFile(nb)
+    of = oracle.OracleFile(nb.view())
+    total = hf.numBatches
+    ctx = renderer.ctx
+    P.Runtime.reset()
+    if ctx.batches_loaded:
+        ctx.stream_unload()
+    renderer.set_camera(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0))
+    p = renderer.render_params()
+    p.lod_percent, p.enable_frustum_culling = 100, 0
+    ctx.stream_begin(hf.header())
+    ctx.set_async_upload(True)
+    try:
+        seen = []
+        for b0 in range(0, total, 35):
+            ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 35, total))])
+            ctx.clear()
+            ctx.render_basic(p)
+            k = ctx.last_frame_batches
+            loaded = ctx.batches_loaded
+            assert k <= (loaded if loaded == total else loaded - 1)
+            seen.append(k)
+            fb = ctx.read_framebuffer(full=True)
+            if k == 0:
+                assert np.all(fb == np.uint64(0xFFFFFFFFFFFFFFFF))
+                continue
+            ofb, ost = of.render_basic(p, first=0, count=k, nthreads=8)
+            assert ctx.stats() == ost
+            assert np.array_equal(fb, ofb), f"frame with {k} of {loaded} handed-over batches"
+        assert seen == sorted(seen)
+        t0 = time.time()
+        while ctx.batches_resident < total:
+            assert time.time() - t0 < 30.0, "loader stream made no progress"
+            time.sleep(0.001)
+        _check_basic(ctx, of, p)
+        assert ctx.last_frame_batches == total
+        _check_hqs(ctx, of, p)
+    finally:
+        ctx.set_async_upload(False)
+        ctx.stream_unload()
