@@ -189,8 +189,11 @@ def main():
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    hbm_read, hbm_copy = ctx.measure_hbm(2 << 30, 5) if rank == 0 else (0.0, 0.0)   # practical ceiling of this box
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "peak_measured": {"stream_read": round(hbm_read, 1), "stream_copy": round(hbm_copy, 1), "unit": "GB/s",
+                                  "frac_of_read": round(achieved / hbm_read, 5) if hbm_read else None},
                 "kernel": "k_render<%s>" % ("basic" if args.method == "basic" else "hqs_depth+hqs_color"),
                 "kernel_ms": round(kernel_ms, 4), "kernel_launches_timed": kernel_launches, "algorithmic_bytes": alg_bytes,
                 "bytes_per_point": round(alg_bytes / max(1, st["points_iterated"]), 4)}

@@ -154,6 +154,11 @@ int64_t pcr_last_frame_batches(const pcr_ctx *ctx);   /* batches drawn by the la
 
 int pcr_timing_begin(pcr_ctx *ctx);
 int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
+/* Practical HBM ceiling of this device, set beside the 8 TB/s spec peak in the roofline: best of `reps`
+ * passes of a streaming read and of a streaming copy (read + write bytes counted) over temporary buffers of `bytes`
+ * each (use >= 1 GiB: the Infinity Cache holds 256 MiB). GB/s = 1e9 bytes per second. */
+int pcr_measure_hbm(pcr_ctx *ctx, size_t bytes, int reps, float *read_gbps, float *copy_gbps);
+
 /* Per-launch duration of the dominant kernel: with every = n > 0, every n-th pcr_render_* call brackets its
  * decode+rasterize kernel (not the prepass) with a HIP event pair on the stream it is launched on (an event pair costs
  * ~5 us of stream time, hence the stride); every = 0 switches it off. pcr_kernel_timing_read synchronises and returns

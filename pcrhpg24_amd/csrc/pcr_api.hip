@@ -855,6 +855,45 @@ int pcr_timing_end(pcr_ctx *c, float *ms)
     return PCR_OK;
 }
 
+int pcr_measure_hbm(pcr_ctx *c, size_t bytes, int reps, float *read_gbps, float *copy_gbps)
+{
+    if (!c || !read_gbps || !copy_gbps || reps <= 0 || bytes < (1u << 20)) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n16 = bytes / 16;
+    hbm_vec4 *a = nullptr, *b = nullptr;
+    uint32_t *sink = nullptr;
+    auto cleanup = [&] { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (sink) (void)hipFree(sink); };
+    if (hipMalloc((void **)&a, n16 * 16) != hipSuccess || hipMalloc((void **)&b, n16 * 16) != hipSuccess ||
+        hipMalloc((void **)&sink, 4) != hipSuccess) {
+        cleanup();
+        return set_err(c, PCR_E_NOMEM, "pcr_measure_hbm: cannot allocate 2 x %zu bytes", n16 * 16);
+    }
+    int rc = PCR_OK;
+    auto run = [&](bool copy, float *out) {
+        const unsigned grid = 256 * 16;          // 16 workgroups of 256 threads per CU
+        float best = 0.0f;
+        for (int r = 0; r < reps + 1; ++r) {     // first pass untimed
+            if (hipEventRecord(c->ev_begin, c->stream) != hipSuccess) { rc = PCR_E_HIP; return; }
+            if (copy) hipLaunchKernelGGL(k_hbm_copy, dim3(grid), dim3(256), 0, c->stream, a, b, n16);
+            else hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(256), 0, c->stream, a, n16, sink);
+            float ms = 0.0f;
+            if (hipEventRecord(c->ev_end, c->stream) != hipSuccess || hipEventSynchronize(c->ev_end) != hipSuccess ||
+                hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) != hipSuccess) { rc = PCR_E_HIP; return; }
+            const float gbps = (float)((copy ? 2.0 : 1.0) * (double)(n16 * 16) / (ms * 1e-3) / 1e9);
+            if (r > 0 && gbps > best) best = gbps;
+        }
+        *out = best;
+    };
+    if (hipMemsetAsync(a, 0x5A, n16 * 16, c->stream) != hipSuccess || hipMemsetAsync(b, 0, n16 * 16, c->stream) != hipSuccess)
+        rc = PCR_E_HIP;
+    if (rc == PCR_OK) run(false, read_gbps);
+    if (rc == PCR_OK) run(true, copy_gbps);
+    (void)hipStreamSynchronize(c->stream);
+    cleanup();
+    if (rc != PCR_OK) return set_err(c, rc, "pcr_measure_hbm: %s", hipGetErrorString(hipGetLastError()));
+    return PCR_OK;
+}
+
 int pcr_kernel_timing_enable(pcr_ctx *c, int every)
 {
     if (!c || every < 0) return PCR_E_ARG;

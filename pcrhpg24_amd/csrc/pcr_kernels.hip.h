@@ -984,6 +984,29 @@ __global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint6
 }
 
 // ------------------------------------------------------------------------------------------------
+// HBM ceiling probes (pcr_measure_hbm): a streaming read (16-byte loads, xor-folded so nothing is optimised away) and a
+// streaming copy, over buffers larger than the 256 MiB Infinity Cache. The practical ceiling the roofline is set beside.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t hbm_vec4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_hbm_read(const hbm_vec4 *src, size_t n16, uint32_t *sink)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    hbm_vec4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        acc ^= __builtin_nontemporal_load(src + i);
+    const uint32_t f = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (f == 0x9E3779B9u) *sink = f;          // practically never: keeps the loads alive
+}
+
+__global__ void __launch_bounds__(256) k_hbm_copy(const hbm_vec4 *src, hbm_vec4 *dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// ------------------------------------------------------------------------------------------------
 // resolve (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
 // ------------------------------------------------------------------------------------------------
 template <bool HQS>

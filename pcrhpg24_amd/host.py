@@ -426,6 +426,12 @@ class Context:
     def last_frame_batches(self) -> int:
         return int(self.lib.pcr_last_frame_batches(self.h))
 
+    def measure_hbm(self, nbytes: int = 2 << 30, reps: int = 5) -> tuple[float, float]:
+        """(streaming read GB/s, streaming copy GB/s) of this device: the practical HBM ceiling."""
+        r, w = C.c_float(), C.c_float()
+        self._chk(self.lib.pcr_measure_hbm(self.h, nbytes, reps, C.byref(r), C.byref(w)), "pcr_measure_hbm")
+        return float(r.value), float(w.value)
+
     def kernel_timing(self, every: int) -> None:
         """Bracket every `every`-th decode+rasterize launch with HIP events (0/False = off)."""
         self._chk(self.lib.pcr_kernel_timing_enable(self.h, int(every)), "pcr_kernel_timing_enable")

@@ -66,8 +66,9 @@ def test_preprocess_cli_equals_library_encoder(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["huffman_mem_iter_cuda", "huffman_hqs"])
-def test_render_cli_matches_oracle(tmp_path, method):
+@pytest.mark.parametrize("method,extra", [("huffman_mem_iter_cuda", []), ("huffman_hqs", []),
+                                          ("huffman_mem_iter_cuda", ["--async-load"])])
+def test_render_cli_matches_oracle(tmp_path, method, extra):
     build.build_tools()
     image, _ = scenes.synth_stream(2_000_000)
     path = tmp_path / "scene.huffman"
@@ -75,7 +76,7 @@ def test_render_cli_matches_oracle(tmp_path, method):
     W, H = 640, 360
     cam = ["-0.15", "-0.57", "1500", "500", "500", "40"]
     res = subprocess.run([build.RENDER_BIN, str(path), "--method", method, "--size", f"{W}x{H}", "--camera", *cam,
-                          "--lod", "0.1", "--dump-fb", str(tmp_path / "fb.u64"), "--dump-rgba", str(tmp_path / "o.ppm")],
+                          "--lod", "0.1", "--dump-fb", str(tmp_path / "fb.u64"), "--dump-rgba", str(tmp_path / "o.ppm"), *extra],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     info = json.loads(res.stdout.strip().splitlines()[-1])
