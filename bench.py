@@ -78,7 +78,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # PCR_FORCE_DIST=1 exercises the multi-GPU code path (torch-owned framebuffers, shared stream, sign-flip +
+    # PCR_FORCE_DIST=1 exercises the multi-GPU code path (torch-owned int64-mergeable framebuffers, shared stream,
     # RCCL all-reduce) with a single rank, which is all a one-GPU box can run
     use_dist = world > 1 or os.environ.get("PCR_FORCE_DIST") == "1"
     if use_dist:

@@ -141,6 +141,21 @@ int   pcr_flip_sign(pcr_ctx *ctx);
 /* ---- measurement ---------------------------------------------------------------------------------
  * HIP events on the context's stream: begin/end bracket any sequence of enqueued calls;
  * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
+/* Ordering between two streams of the context's device without the system-scope release a default HIP event carries
+ * (which writes the L2 back: the 16.6 MB framebuffer the next kernel is about to read). slot in [0, 8). A frame rendered
+ * on one stream and merged on another uses two of these per frame. stream NULL = the context's stream. */
+int pcr_fence_record(pcr_ctx *ctx, int slot, void *hip_stream);
+int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
+
+/* Multi-GPU merges through a library that only has a SIGNED 64-bit MIN (RCCL as torch.distributed exposes it): with
+ * on = 1, pcr_clear writes INT64_MAX (0x7FFF...F) into empty pixels instead of the reference's all-ones word. Every key a
+ * point can produce has a clear top bit (the depth half is the bit pattern of a positive float), so the kernels' unsigned
+ * atomicMin, the resolves (they test the low half against 0xFFFFFFFF) and the HQS depth test (both words read as NaN)
+ * behave exactly as before, signed and unsigned order agree on the whole framebuffer, and no sign-flip passes are
+ * needed around the collective. pcr_read_framebuffer reports empty pixels as all-ones in either mode. Takes effect with
+ * the next pcr_clear. */
+int pcr_set_int64_mergeable(pcr_ctx *ctx, int on);
+
 /* Asynchronous loader. Off (default): pcr_upload_batches enqueues its copies and the transcode on the
  * context's stream, in order with the frames, and a frame draws every batch handed over so far, as the reference's
  * process() does (HuffmanLasLoader.cpp:301-313). On: they run on a loader stream of the context's own, the call

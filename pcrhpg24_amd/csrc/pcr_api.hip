@@ -64,6 +64,9 @@ struct pcr_ctx {
     std::vector<hipEvent_t> loader_events;      // recycled
     int64_t batches_resident = 0;
     int64_t last_frame_batches = 0;
+    uint64_t empty_key = ~0ull;                 // what pcr_clear writes (pcr_set_int64_mergeable)
+    static constexpr int FENCES = 8;
+    hipEvent_t fence[FENCES] = {};              // pcr_fence_record / pcr_fence_wait: device-scope ordering between streams
     int64_t visible_batches() const { return async_upload ? batches_resident : batches_loaded; }
 
     // resource of the 10-10-10 path (ComputeLasData)
@@ -290,6 +293,7 @@ void pcr_destroy(pcr_ctx *c)
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (hipEvent_t e : c->loader_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->fence) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -598,9 +602,16 @@ int pcr_clear(pcr_ctx *c)
     // after a colour pass (or when the buffers changed hands), which saves two 16.6 MB fills per basic frame at 1080p
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
-    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, c->stream, c->fb, rg, ba, c->fb_elems);
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, c->stream, c->fb, rg, ba, c->fb_elems, c->empty_key);
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
+    return PCR_OK;
+}
+
+int pcr_set_int64_mergeable(pcr_ctx *c, int on)
+{
+    if (!c) return PCR_E_ARG;
+    c->empty_key = on ? 0x7FFFFFFFFFFFFFFFull : ~0ull;
     return PCR_OK;
 }
 
@@ -770,6 +781,8 @@ int pcr_read_framebuffer(pcr_ctx *c, uint64_t *host, size_t n)
     if (!c->fb || n > c->fb_elems) return set_err(c, PCR_E_ARG, "bad framebuffer read of %zu elements", n);
     HIP_TRY(c, hipMemcpyAsync(host, c->fb, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->empty_key != ~0ull)                   // the caller always sees the reference's empty word
+        for (size_t i = 0; i < n; ++i) if (host[i] == c->empty_key) host[i] = ~0ull;
     return PCR_OK;
 }
 
@@ -802,10 +815,28 @@ int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
     if (!c) return PCR_E_ARG;
     if (!c->own_fb) return set_err(c, PCR_E_ARG, "call pcr_set_image_size first");
     // pointers are captured by value at enqueue time: switching them does not disturb work already enqueued
-    c->accum_dirty = true;
+    uint64_t *nrg = rg ? (uint64_t *)rg : c->own_rg, *nba = ba ? (uint64_t *)ba : c->own_ba;
+    if (nrg != c->rg || nba != c->ba) c->accum_dirty = true;     // unknown contents: the next pcr_clear zeroes them
     c->fb = fb ? (uint64_t *)fb : c->own_fb;
-    c->rg = rg ? (uint64_t *)rg : c->own_rg;
-    c->ba = ba ? (uint64_t *)ba : c->own_ba;
+    c->rg = nrg;
+    c->ba = nba;
+    return PCR_OK;
+}
+
+int pcr_fence_record(pcr_ctx *c, int slot, void *hip_stream)
+{
+    if (!c || slot < 0 || slot >= pcr_ctx::FENCES) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->fence[slot]) HIP_TRY(c, hipEventCreateWithFlags(&c->fence[slot], hipEventDisableTiming | hipEventReleaseToDevice));
+    HIP_TRY(c, hipEventRecord(c->fence[slot], hip_stream ? (hipStream_t)hip_stream : c->stream));
+    return PCR_OK;
+}
+
+int pcr_fence_wait(pcr_ctx *c, int slot, void *hip_stream)
+{
+    if (!c || slot < 0 || slot >= pcr_ctx::FENCES) return PCR_E_ARG;
+    if (!c->fence[slot]) return PCR_OK;          // never recorded: nothing to wait for
+    HIP_TRY(c, hipStreamWaitEvent(hip_stream ? (hipStream_t)hip_stream : c->stream, c->fence[slot], 0));
     return PCR_OK;
 }
 

@@ -967,17 +967,17 @@ __global__ void __launch_bounds__(256) k_las_resolve(int width, int height, cons
 // CLEAR block (huffman_hqs.h:266-270): fb <- all ones, and RG/BA <- 0 when a colour pass has written them; one launch,
 // 16-byte stores
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n)
+__global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty)
 {
     const size_t pairs = n / 2, stride = (size_t)gridDim.x * blockDim.x;
-    const ulonglong2 ones = make_ulonglong2(~0ull, ~0ull), zero = make_ulonglong2(0ull, 0ull);
+    const ulonglong2 ones = make_ulonglong2(empty, empty), zero = make_ulonglong2(0ull, 0ull);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
         reinterpret_cast<ulonglong2 *>(fb)[i] = ones;
         if (rg) reinterpret_cast<ulonglong2 *>(rg)[i] = zero;
         if (ba) reinterpret_cast<ulonglong2 *>(ba)[i] = zero;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        fb[n - 1] = ~0ull;
+        fb[n - 1] = empty;
         if (rg) rg[n - 1] = 0;
         if (ba) ba[n - 1] = 0;
     }

@@ -10,8 +10,11 @@ A reduce moves half the bytes of an all-reduce over the point-to-point xGMI link
 finished frame on every rank instead.
 
 torch.distributed is the transport (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
-tests). It exposes signed int64 only, so the u64 min is computed as a signed min on sign-flipped words
-(x ^ 1<<63 is an order isomorphism u64 -> i64); the flips run in libpcr_hip.so on the GPU path.
+tests). It exposes signed int64 only. On the GPU path the framebuffer is made int64-mergeable instead of being
+sign-flipped around every collective: empty pixels are cleared to INT64_MAX rather than all-ones
+(`pcr_set_int64_mergeable`), every key a point produces has a clear top bit, so signed and unsigned order agree. The
+numpy forms used by the gloo tests take arbitrary u64 words and flip the sign bit (x ^ 1<<63 is an order isomorphism
+u64 -> i64).
 """
 from __future__ import annotations
 
@@ -90,7 +93,7 @@ def exchange_shard_heads(head_enc: np.ndarray, head_sep: np.ndarray, device, gro
 class DeviceFrame:
     """Framebuffers owned by torch (so RCCL can reduce them in place) and lent to a pcr context."""
 
-    def __init__(self, ctx, width: int, height: int, device):
+    def __init__(self, ctx, width: int, height: int, device, accum: bool = True):
         import torch
         from ._native import fb_elems
         n = fb_elems(width, height)
@@ -98,22 +101,26 @@ class DeviceFrame:
         self.ctx = ctx
         self.device = device
         self.fb = torch.empty(n, dtype=torch.int64, device=device)
-        self.acc = torch.zeros(2 * n2, dtype=torch.int64, device=device)   # RG | BA: one collective for both
-        self.rg = self.acc[:n]
-        self.ba = self.acc[n2:n2 + n]
+        # RG | BA: one collective for both. A frame of the basic method has none (accum=False): the context keeps its own,
+        # which pcr_clear then does not have to zero again every time the frame is bound
+        self.acc = torch.zeros(2 * n2, dtype=torch.int64, device=device) if accum else None
+        self.rg = self.acc[:n] if accum else None
+        self.ba = self.acc[n2:n2 + n] if accum else None
 
     def bind(self, stream=None):
         """Make this frame the context's render target; pcr work goes to `stream` (default: torch's current)."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         self.ctx.set_stream(s.cuda_stream)
-        self.ctx.use_external_buffers(self.fb.data_ptr(), self.rg.data_ptr(), self.ba.data_ptr())
+        self.ctx.use_external_buffers(self.fb.data_ptr(), self.rg.data_ptr() if self.rg is not None else 0,
+                                      self.ba.data_ptr() if self.ba is not None else 0)
+        # torch's NCCL/RCCL binding has no uint64: the frame is reduced as int64, which orders it correctly once empty
+        # pixels are INT64_MAX instead of all-ones (every real key has a clear top bit) -- no sign-flip passes
+        self.ctx.set_int64_mergeable(True)
 
     def allreduce_min(self, group=None):
         import torch.distributed as dist
-        self.ctx.flip_sign()
         dist.all_reduce(self.fb, op=dist.ReduceOp.MIN, group=group)
-        self.ctx.flip_sign()
 
     def allreduce_sum(self, group=None):
         import torch.distributed as dist
@@ -122,12 +129,8 @@ class DeviceFrame:
     def reduce_min(self, dst: int = 0, group=None) -> bool:
         """u64 min reduce to rank `dst`; returns whether this rank holds the merged frame afterwards."""
         import torch.distributed as dist
-        self.ctx.flip_sign()
         dist.reduce(self.fb, dst=dst, op=dist.ReduceOp.MIN, group=group)
-        mine = dist.get_rank(group) == dst
-        if mine:
-            self.ctx.flip_sign()                    # the other ranks' copies are cleared by the next frame anyway
-        return mine
+        return dist.get_rank(group) == dst
 
     def reduce_sum(self, dst: int = 0, group=None) -> bool:
         import torch.distributed as dist
@@ -137,6 +140,7 @@ class DeviceFrame:
     def release(self):
         self.ctx.synchronize()
         self.ctx.use_external_buffers(0, 0, 0)
+        self.ctx.set_int64_mergeable(False)
         self.ctx.set_stream(0)
 
 
@@ -172,39 +176,38 @@ def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: in
 
 
 class PipelinedBasicRenderer:
-    """Basic method over shards with the exchange step overlapped: frame k is merged (sign flip, RCCL min
-    all-reduce, flip back, resolve) on a communication stream while frame k+1 is already being decoded and
+    """Basic method over shards with the exchange step overlapped: frame k is merged (RCCL min reduce or
+    all-reduce, resolve) on a communication stream while frame k+1 is already being decoded and
     rasterized into the other of two framebuffers on the compute stream. HIP events order the two streams; results
     are the same as the one-stream form, one frame later."""
 
     def __init__(self, ctx, width: int, height: int, device, group=None, merge: str = "reduce"):
         import torch
         self.ctx, self.device, self.group, self.merge = ctx, device, group, merge
-        self.frames = [DeviceFrame(ctx, width, height, device), DeviceFrame(ctx, width, height, device)]
+        self.frames = [DeviceFrame(ctx, width, height, device, accum=False), DeviceFrame(ctx, width, height, device, accum=False)]
         self.compute = torch.cuda.Stream(device)
         self.comm = torch.cuda.Stream(device, priority=-1)   # its small kernels should not queue behind a frame's 1526 workgroups
-        self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
-        self.merged = [torch.cuda.Event(), torch.cuda.Event()]
+        # stream-to-stream ordering goes through the context's device-scope fences (slots 0,1: frame i rendered; 2,3: frame
+        # i merged): a default event releases to system scope, i.e. writes the L2 with the framebuffer in it back
         self.k = 0
-        for e in self.merged:
-            e.record(self.comm)
 
     def step(self, params):
         import torch
         i = self.k & 1
         f = self.frames[i]
-        self.compute.wait_event(self.merged[i])        # this framebuffer's previous merge + resolve are done
+        cs, ms = self.compute.cuda_stream, self.comm.cuda_stream
+        self.ctx.fence_wait(2 + i, cs)                 # this framebuffer's previous merge + resolve are done
         f.bind(self.compute)
         self.ctx.clear()
         self.ctx.render_basic(params)
-        self.rendered[i].record(self.compute)
-        self.comm.wait_event(self.rendered[i])
+        self.ctx.fence_record(i, cs)
+        self.ctx.fence_wait(i, ms)
         with torch.cuda.stream(self.comm):             # RCCL orders itself against torch's current stream
             f.bind(self.comm)
             final = f.reduce_min(0, self.group) if self.merge == "reduce" else (f.allreduce_min(self.group) or True)
             if final:
                 self.ctx.resolve_basic(params)
-            self.merged[i].record(self.comm)
+            self.ctx.fence_record(2 + i, ms)
         self.k += 1
 
     def last_frame(self) -> DeviceFrame:

@@ -414,6 +414,16 @@ class Context:
     def flip_sign(self):
         self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
 
+    def fence_record(self, slot: int, hip_stream: int = 0) -> None:
+        self._chk(self.lib.pcr_fence_record(self.h, slot, hip_stream), "pcr_fence_record")
+
+    def fence_wait(self, slot: int, hip_stream: int = 0) -> None:
+        self._chk(self.lib.pcr_fence_wait(self.h, slot, hip_stream), "pcr_fence_wait")
+
+    def set_int64_mergeable(self, on: bool) -> None:
+        """Empty pixels as INT64_MAX so that a signed 64-bit MIN collective orders the framebuffer (pcr_hip.h)."""
+        self._chk(self.lib.pcr_set_int64_mergeable(self.h, int(on)), "pcr_set_int64_mergeable")
+
     def set_async_upload(self, on: bool) -> None:
         """Loader copies + transcode on the context's loader stream; frames draw what has arrived (pcr_hip.h)."""
         self._chk(self.lib.pcr_set_async_upload(self.h, int(on)), "pcr_set_async_upload")
