@@ -147,6 +147,17 @@ int   pcr_flip_sign(pcr_ctx *ctx);
 int pcr_fence_record(pcr_ctx *ctx, int slot, void *hip_stream);
 int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
 
+/* HBM layout the context gives the next stream it loads (pcr_stream_begin fixes it). Both hold the same bits and decode to
+ * the same points; the Huffman decode runs every frame in both.
+ *   PCR_LAYOUT_WORDS          per chain the sequence of 32-bit words it consumes (320 B per chain allocated, ~3 B per
+ *                             point read): the decode keeps a five-word queue per lane.
+ *   PCR_LAYOUT_POINT_WINDOWS  (default) additionally, per point, the 64 bits of its chain's stream that start at the
+ *                             point's first bit (8 B per point): no queue in the decode, ~20 % fewer instructions per
+ *                             point for ~2.5x the bytes per frame, on a kernel that is issue bound, not HBM bound. */
+#define PCR_LAYOUT_WORDS 0
+#define PCR_LAYOUT_POINT_WINDOWS 1
+int pcr_set_stream_layout(pcr_ctx *ctx, int layout);
+
 /* Multi-GPU merges through a library that only has a SIGNED 64-bit MIN (RCCL as torch.distributed exposes it): with
  * on = 1, pcr_clear writes INT64_MAX (0x7FFF...F) into empty pixels instead of the reference's all-ones word. Every key a
  * point can produce has a clear top bit (the depth half is the bit pattern of a positive float), so the kernels' unsigned

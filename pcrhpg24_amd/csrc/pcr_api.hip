@@ -46,7 +46,10 @@ struct pcr_ctx {
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
     uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
     uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
-    int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words are final
+    uint2 *d_point_windows = nullptr;           // PCR_LAYOUT_POINT_WINDOWS: 64-bit view per point (k_transcode), PW_ROWS x 1024 per batch
+    int layout = PCR_LAYOUT_POINT_WINDOWS;      // of the stream being loaded (pcr_set_stream_layout, fixed at pcr_stream_begin)
+    int next_layout = PCR_LAYOUT_POINT_WINDOWS;
+    int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words / d_point_windows are final
     pcr_render_stats *d_stats = nullptr;        // PCR_STATS_PARTIALS partial records, one per prepass workgroup
     int stats_partials = 0;                     // how many the last render launch wrote
     // pinned staging arenas of the loader (double-buffered)
@@ -136,7 +139,7 @@ void free_stream_buffers(pcr_ctx *c)
     c->batches_resident = 0;
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
-    dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); c->transcoded = 0;
+    dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); c->transcoded = 0;
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
@@ -183,6 +186,7 @@ StreamView make_stream_view(pcr_ctx *c)
     s.separate = c->d_separate; s.separate_sizes = c->d_sep_sizes; s.table_values = c->d_table_values;
     s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors;
     s.lane_words = c->d_lane_words; s.batch_flags = c->d_batch_flags; s.packed_table = c->d_packed_table;
+    s.point_windows = c->d_point_windows;
     s.encoded_words = c->enc_words; s.separate_words = c->sep_words;
     s.num_batches = c->visible_batches(); s.batch_index_base = c->batch_index_base;
     return s;
@@ -209,7 +213,8 @@ void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
     const int64_t end = include_provisional ? loaded : final_end;
     if (end > c->transcoded) {
         hipLaunchKernelGGL(k_transcode, dim3((unsigned)(end - c->transcoded)), dim3(PCR_WORKGROUP_SIZE), 0, st,
-                           make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, (int)c->transcoded);
+                           make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows,
+                           (int)c->transcoded);
         c->transcoded = std::max(c->transcoded, final_end);
     }
 }
@@ -230,7 +235,10 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
     if (timed) HIP_TRY(c, hipEventRecord(c->kt_begin[slot], c->stream));
-    hipLaunchKernelGGL(k_render<MODE>, dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    if (c->layout == PCR_LAYOUT_POINT_WINDOWS)
+        hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
     if (timed) { HIP_TRY(c, hipEventRecord(c->kt_end[slot], c->stream)); ++c->kt_samples; }
     if (c->kt_every > 0) ++c->kt_launches;
     HIP_TRY(c, hipGetLastError());
@@ -340,11 +348,14 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32)) ||
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB)) || (rc = dalloc_zero(c, c->d_win, nB)) ||
         (rc = dalloc_zero(c, c->d_lane_words, nB * LW_ROWS * PCR_WORKGROUP_SIZE)) || (rc = dalloc_zero(c, c->d_batch_flags, nB)) ||
-        (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE))) {
+        (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE)) ||
+        (c->next_layout == PCR_LAYOUT_POINT_WINDOWS &&
+         (rc = dalloc_zero(c, c->d_point_windows, (nB * PW_ROWS + PW_GUARD_ROWS) * PCR_WORKGROUP_SIZE)))) {
         free_stream_buffers(c);
         return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->layout = c->next_layout;
     c->stream_open = true;
     return PCR_OK;
 }
@@ -530,6 +541,14 @@ int pcr_stream_unload(pcr_ctx *c)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_stream_buffers(c);
+    return PCR_OK;
+}
+
+int pcr_set_stream_layout(pcr_ctx *c, int layout)
+{
+    if (!c) return PCR_E_ARG;
+    if (layout != PCR_LAYOUT_WORDS && layout != PCR_LAYOUT_POINT_WINDOWS) return set_err(c, PCR_E_ARG, "unknown stream layout %d", layout);
+    c->next_layout = layout;         // the stream that is loaded keeps the layout it was loaded with
     return PCR_OK;
 }
 

@@ -38,6 +38,16 @@ constexpr int WIN_PIXELS_HQS = 1843;             // colour pass: {RG u64, BA u64
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
 constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
+// Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 64 bits of the chain's own
+// bit stream that start at the point's first bit -- its three symbols (<= 36 bits) and the look-ahead of the next point's
+// first symbol (12 more) lie inside. Row i holds the windows of the batch's 1024 chains: every lane of k_render reads row
+// i at point i (8 bytes per lane, 512 contiguous bytes per wave), with no word queue to maintain. 8 bytes per point of
+// HBM instead of the ~3 the packed words take: bytes traded for instructions on a kernel that is issue bound with 5x
+// of HBM bandwidth to spare. PW_GUARD_ROWS: k_render requests two rows ahead.
+constexpr int PW_ROWS        = PCR_POINTS_PER_THREAD;
+constexpr uint32_t PW_ROW_BYTES = PCR_WORKGROUP_SIZE * 8;
+constexpr int PW_GUARD_ROWS  = 2;
+enum { LAYOUT_WORDS = 0, LAYOUT_POINT_WINDOWS = 1 };
 // batch_flags: set when some chain of the batch can meet an in-table value outside the packed entry's range or read an
 // escape word outside k_render's LDS pool (k_transcode walks all 192 symbols of every chain, garbage tails included)
 constexpr uint32_t BF_GENERIC_SLOW_PATH = 1u;
@@ -61,6 +71,7 @@ struct StreamView {
     const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
+    const uint2    *point_windows;    // [(nB*PW_ROWS + PW_GUARD_ROWS)*1024] or NULL (layout), written by k_transcode
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
@@ -311,7 +322,7 @@ __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lby
 // without checking (batch_flags).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
-                                                                  uint32_t *packed_table, int first_batch)
+                                                                  uint32_t *packed_table, uint2 *point_windows, int first_batch)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -355,9 +366,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     uint32_t ep = 64, next_cross = 2 * CHUNK_WORDS;         // already_read (:418)
     uint32_t sft = 32 + 20;                                 // cur_bits (:419) + 20: (bits >> sft) & 0xFFF is the key of :431-433
     uint32_t nesc = 0;
+    uint2 *pw = point_windows ? point_windows + (size_t)b * PW_ROWS * PCR_WORKGROUP_SIZE + tid : nullptr;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < PCR_POINTS_PER_THREAD * 3; ++k) {   // :428-430
+        // first bit of point k/3 in the chain's own word sequence: `bits` holds rows row-2 and row-1, of which 52 - sft
+        // bits are consumed (parked in the window slot until the words behind it are known, see below)
+        if (pw && k % 3 == 0) pw[(size_t)(k / 3) * PCR_WORKGROUP_SIZE].x = 32u * (row - 2u) + (52u - sft);
         const uint32_t l = s_len[(uint32_t)(bits >> sft) & 0xFFFu];
         sft -= l & 0x7Fu;                                   // :435-439
         nesc += l >> 7;                                     // :438
@@ -392,12 +407,30 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     if (nesc && sp0 + nesc > esc_lds) generic = true;
     const int any = __syncthreads_or(generic ? 1 : 0);
     if (tid == 0) batch_flags[b] = any ? BF_GENERIC_SLOW_PATH : 0u;
+
+    // Point windows: 64 bits of my word sequence from each point's first bit. A point's window can reach two words past
+    // the last word the walk had fetched when the point began, so they are cut once the whole sequence is written
+    // (rows the chain never received read as what the buffer held -- bits no symbol of the point can reach).
+    if (pw) {
+        __threadfence();            // my own stores above (lane_words column, parked positions) before I read them back
+#pragma unroll 4
+        for (int i = 0; i < PW_ROWS; ++i) {
+            const uint32_t pos = pw[(size_t)i * PCR_WORKGROUP_SIZE].x;
+            const uint32_t r = pos >> 5, o = pos & 31u;
+            const uint32_t a0 = out[(size_t)r * PCR_WORKGROUP_SIZE], a1 = out[(size_t)(r + 1) * PCR_WORKGROUP_SIZE],
+                           a2 = out[(size_t)(r + 2) * PCR_WORKGROUP_SIZE];
+            // alignbit(hi, lo, s) = low 32 bits of (hi:lo) >> (s & 31): s = 32 - o cuts 32 bits starting o bits into hi
+            const uint32_t hi = o ? __builtin_amdgcn_alignbit(a0, a1, 32u - o) : a0;
+            const uint32_t lo = o ? __builtin_amdgcn_alignbit(a1, a2, 32u - o) : a1;
+            pw[(size_t)i * PCR_WORKGROUP_SIZE] = make_uint2(lo, hi);     // little-endian u64: x = low half
+        }
+    }
 }
 
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int MODE>
+template <int MODE, int LAYOUT>
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two workgroups per CU -> <= 64 VGPRs
 {
     const uint32_t b = blockIdx.x;
@@ -477,14 +510,26 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // symbols (<= 36 bits) and the look-ahead of the next point's first symbol (12 more) index into it, and the words
     // that ran dry are retired afterwards: no refill test, load or wait inside the symbol steps.
     // (Cur/Next of :416-419 are the first two words; the stand-in w0 = 0 is "fully consumed" from the start.)
+    // LAYOUT_POINT_WINDOWS: the 64-bit view of every point was cut by k_transcode; row i of point_windows is read at
+    // point i (requested two points earlier) and there is no queue.
     const char *lwb = reinterpret_cast<const char *>(a.s.lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE);   // uniform
     auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + byte_off); };
+    const char *pwb = reinterpret_cast<const char *>(a.s.point_windows + (size_t)b * PW_ROWS * PCR_WORKGROUP_SIZE); // uniform
+    auto pw_load = [&](uint32_t byte_off) -> uint64_t { return *reinterpret_cast<const uint64_t *>(pwb + byte_off); };
     uint32_t lwo = tid * 4;                                 // byte offset of my column in the row of far0
-    uint32_t w0 = 0, w1 = lw_load(lwo), w2 = lw_load(lwo + LW_ROW_BYTES);
-    uint32_t far0 = lw_load(lwo + 2 * LW_ROW_BYTES), far1 = lw_load(lwo + 3 * LW_ROW_BYTES);
-    lwo += 2 * LW_ROW_BYTES;
-    uint32_t spare = 0;
-    uint64_t bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
+    uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
+    uint64_t bits, nwin = 0;
+    if (LAYOUT == LAYOUT_WORDS) {
+        w1 = lw_load(lwo); w2 = lw_load(lwo + LW_ROW_BYTES);
+        far0 = lw_load(lwo + 2 * LW_ROW_BYTES); far1 = lw_load(lwo + 3 * LW_ROW_BYTES);
+        lwo += 2 * LW_ROW_BYTES;
+        bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
+    } else {
+        lwo = tid * 8;                                      // byte offset of my column in the row of nwin
+        bits = pw_load(lwo);
+        lwo += PW_ROW_BYTES;
+        nwin = pw_load(lwo);
+    }
     constexpr uint32_t SFT0 = 50;                           // (bits >> 50) & 0x3FFC = 4 x the top 12 bits of the view
     uint32_t sft = SFT0;
 
@@ -566,6 +611,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // whole point ago), request the next two, cut the next view. u = spare - consumed + 64 lies in [28, 95].
 #define PCR_ADVANCE_WORD_WINDOW()                                                          \
     do {                                                                                   \
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) {                                              \
+            bits = nwin;                                                                   \
+            sft = SFT0;                                                                    \
+            break;                                                                         \
+        }                                                                                  \
         const uint32_t u_ = spare + sft + (64u - SFT0);                                    \
         const uint32_t k_ = u_ >> 5;               /* 2: no word retired, 1: one, 0: two */ \
         spare = u_ & 31u;                                                                  \
@@ -609,6 +659,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
       const int seg_end = min(seg + 16, npr_run);
 #pragma unroll 1
       for (int i = seg; i < seg_end; ++i) {                                 // :428
+        uint64_t fetched = 0;
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) {
+            // row i+2, requested at the top of point i and taken over at its very end: a whole point of latency cover
+            // (past row 63 lie the next batch's rows or the guard)
+            lwo += PW_ROW_BYTES;
+            fetched = pw_load(lwo);
+        }
         uint32_t dec[3];
         {
 #pragma unroll
@@ -719,6 +776,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         pend_depth = __float_as_uint(qw);                                   // :287
         if (widx != NO_PIXEL)      pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[widx] << 32 : s_win[widx];   // :297 on the LDS copy
         else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
       }
     }
     if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr_run - 1);

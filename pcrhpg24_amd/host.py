@@ -414,6 +414,12 @@ class Context:
     def flip_sign(self):
         self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
 
+    LAYOUT_WORDS, LAYOUT_POINT_WINDOWS = 0, 1
+
+    def set_stream_layout(self, layout: int) -> None:
+        """HBM layout of the next stream this context loads (pcr_hip.h: PCR_LAYOUT_*)."""
+        self._chk(self.lib.pcr_set_stream_layout(self.h, int(layout)), "pcr_set_stream_layout")
+
     def fence_record(self, slot: int, hip_stream: int = 0) -> None:
         self._chk(self.lib.pcr_fence_record(self.h, slot, hip_stream), "pcr_fence_record")
 
