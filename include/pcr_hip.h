@@ -157,6 +157,14 @@ int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
 #define PCR_LAYOUT_WORDS 0
 #define PCR_LAYOUT_POINT_WINDOWS 1
 int pcr_set_stream_layout(pcr_ctx *ctx, int layout);
+/* A stream loaded with PCR_LAYOUT_POINT_WINDOWS keeps the packed words too, so either decode variant can draw a frame.
+ * AUTO (default): the point-window variant while the image has at most 4608 pixels (one LDS framebuffer window) per loaded
+ * batch, the packed-words variant beyond that, where the frame is bound by global framebuffer traffic and the smaller
+ * stream wins. WORDS / POINT_WINDOWS force one (the latter only where the windows are resident). Results are identical. */
+#define PCR_VARIANT_AUTO 0
+#define PCR_VARIANT_WORDS 1
+#define PCR_VARIANT_POINT_WINDOWS 2
+int pcr_set_render_variant(pcr_ctx *ctx, int variant);
 
 /* Multi-GPU merges through a library that only has a SIGNED 64-bit MIN (RCCL as torch.distributed exposes it): with
  * on = 1, pcr_clear writes INT64_MAX (0x7FFF...F) into empty pixels instead of the reference's all-ones word. Every key a

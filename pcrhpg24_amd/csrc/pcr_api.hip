@@ -49,6 +49,7 @@ struct pcr_ctx {
     uint2 *d_point_windows = nullptr;           // PCR_LAYOUT_POINT_WINDOWS: 64-bit view per point (k_transcode), PW_ROWS x 1024 per batch
     int layout = PCR_LAYOUT_POINT_WINDOWS;      // of the stream being loaded (pcr_set_stream_layout, fixed at pcr_stream_begin)
     int next_layout = PCR_LAYOUT_POINT_WINDOWS;
+    int variant = PCR_VARIANT_AUTO;             // which k_render variant draws a stream that has both layouts resident
     int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words / d_point_windows are final
     pcr_render_stats *d_stats = nullptr;        // PCR_STATS_PARTIALS partial records, one per prepass workgroup
     int stats_partials = 0;                     // how many the last render launch wrote
@@ -235,7 +236,13 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
     if (timed) HIP_TRY(c, hipEventRecord(c->kt_begin[slot], c->stream));
-    if (c->layout == PCR_LAYOUT_POINT_WINDOWS)
+    // With the point windows resident both variants can draw the frame (the packed words stay in HBM). The windows
+    // variant trades bytes for instructions, which pays while the scatter runs in the LDS framebuffer windows; when the
+    // batches' rectangles outgrow those (more pixels per batch than a window holds: 4096x4096 over 1526 batches), the frame
+    // is bound by global framebuffer traffic and the 3 B per point of the packed words win (0.70 ms against 0.75 ms).
+    const bool windows = c->layout == PCR_LAYOUT_POINT_WINDOWS && c->variant != PCR_VARIANT_WORDS &&
+                         (c->variant == PCR_VARIANT_POINT_WINDOWS || (int64_t)c->width * c->height <= nB * (int64_t)WIN_PIXELS);
+    if (windows)
         hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
     else
         hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
@@ -549,6 +556,15 @@ int pcr_set_stream_layout(pcr_ctx *c, int layout)
     if (!c) return PCR_E_ARG;
     if (layout != PCR_LAYOUT_WORDS && layout != PCR_LAYOUT_POINT_WINDOWS) return set_err(c, PCR_E_ARG, "unknown stream layout %d", layout);
     c->next_layout = layout;         // the stream that is loaded keeps the layout it was loaded with
+    return PCR_OK;
+}
+
+int pcr_set_render_variant(pcr_ctx *c, int variant)
+{
+    if (!c) return PCR_E_ARG;
+    if (variant != PCR_VARIANT_AUTO && variant != PCR_VARIANT_WORDS && variant != PCR_VARIANT_POINT_WINDOWS)
+        return set_err(c, PCR_E_ARG, "unknown render variant %d", variant);
+    c->variant = variant;
     return PCR_OK;
 }
 

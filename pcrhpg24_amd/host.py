@@ -420,6 +420,12 @@ class Context:
         """HBM layout of the next stream this context loads (pcr_hip.h: PCR_LAYOUT_*)."""
         self._chk(self.lib.pcr_set_stream_layout(self.h, int(layout)), "pcr_set_stream_layout")
 
+    VARIANT_AUTO, VARIANT_WORDS, VARIANT_POINT_WINDOWS = 0, 1, 2
+
+    def set_render_variant(self, variant: int) -> None:
+        """Which decode variant draws a stream that has both layouts resident (pcr_hip.h: PCR_VARIANT_*)."""
+        self._chk(self.lib.pcr_set_render_variant(self.h, int(variant)), "pcr_set_render_variant")
+
     def fence_record(self, slot: int, hip_stream: int = 0) -> None:
         self._chk(self.lib.pcr_fence_record(self.h, slot, hip_stream), "pcr_fence_record")
 

@@ -38,9 +38,10 @@ def load(ctx, image):
     return f
 
 
-@pytest.fixture()
-def ctx():
+@pytest.fixture(params=["point_windows", "words"])
+def ctx(request):
     c = P.Context(0)
+    c.set_render_variant(P.Context.VARIANT_POINT_WINDOWS if request.param == "point_windows" else P.Context.VARIANT_WORDS)
     yield c
     c.close()
 

@@ -10,9 +10,16 @@ pytestmark = pytest.mark.gpu
 W, H = 640, 360
 
 
-@pytest.fixture(scope="module")
-def renderer():
+# Every test of this module runs once per decode variant: "point_windows" (the default layout's own kernel), "words" on
+# the same resident stream (what PCR_VARIANT_AUTO picks for images with few batches per pixel, as here), and "words_only"
+# on a stream loaded with PCR_LAYOUT_WORDS (no point windows in HBM at all).
+@pytest.fixture(scope="module", params=["point_windows", "words", "words_only"])
+def renderer(request):
     r = P.Renderer(W, H, device=0)
+    if request.param == "words_only":
+        r.ctx.set_stream_layout(P.Context.LAYOUT_WORDS)
+    else:
+        r.ctx.set_render_variant(P.Context.VARIANT_POINT_WINDOWS if request.param == "point_windows" else P.Context.VARIANT_WORDS)
     yield r
     r.ctx.close()
 

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--variant", choices=["auto", "words", "point_windows"], default="auto", help="decode variant (pcr_set_render_variant)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     image, _ = scenes.synth_stream(2_000_000)
@@ -36,6 +37,7 @@ def main():
     ctxs = {}
     for (w, h) in sizes:
         ctx = P.Context(0)
+        ctx.set_render_variant({"auto": 0, "words": 1, "point_windows": 2}[args.variant])
         ctx.set_image_size(w, h)
         ctx.stream_begin(hf.header(), 0)
         ctx.upload_batches(0, [hf.blob(b) for b in range(hf.numBatches)])

@@ -55,10 +55,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--variant", choices=["auto", "words", "point_windows"], default="auto", help="decode variant (pcr_set_render_variant)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     W, H = 480, 270
     ctx = P.Context(0)
+    ctx.set_render_variant({"auto": 0, "words": 1, "point_windows": 2}[args.variant])
     ctx.set_image_size(W, H)
     bad = enc_bad = 0
     t0 = time.time()
