@@ -99,6 +99,14 @@ def hip_lib() -> C.CDLL:
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with `python -m pcrhpg24_amd.build` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # One HIP runtime per process: torch ships its own libamdhip64/libhsa-runtime64 under torch/lib with the same
+        # SONAMEs as /opt/rocm's. Whichever copy is mapped first serves both torch and this library; with ROCm's mapped
+        # first, torch's own device initialisation later fails ("No HIP GPUs are available"). torch is the plumbing for
+        # streams and RCCL on the multi-GPU path, so its copy goes first whenever torch is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         lib.pcr_last_error.restype = C.c_char_p
         lib.pcr_last_error.argtypes = [C.c_void_p]
