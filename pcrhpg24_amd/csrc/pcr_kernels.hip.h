@@ -666,6 +666,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             lwo += PW_ROW_BYTES;
             fetched = pw_load(lwo);
         }
+#ifdef PCR_EXP_EXTRA_LOAD   /* experiment: 4 (or 8) more bytes of HBM traffic per point, consumed at the end of the point */
+        const uint32_t extra0 = lw_load((uint32_t)i * LW_ROW_BYTES + tid * 4);
+#if PCR_EXP_EXTRA_LOAD > 1
+        const uint32_t extra1 = lw_load((uint32_t)(i + 8) * LW_ROW_BYTES + tid * 4);
+#endif
+#endif
         uint32_t dec[3];
         {
 #pragma unroll
@@ -777,6 +783,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         if (widx != NO_PIXEL)      pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[widx] << 32 : s_win[widx];   // :297 on the LDS copy
         else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
         if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
+#ifdef PCR_EXP_EXTRA_LOAD
+        asm volatile("; extra load consumed %0" :: "v"(extra0));
+#if PCR_EXP_EXTRA_LOAD > 1
+        asm volatile("; extra load consumed %0" :: "v"(extra1));
+#endif
+#endif
       }
     }
     if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr_run - 1);
