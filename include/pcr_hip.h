@@ -166,6 +166,15 @@ int pcr_set_stream_layout(pcr_ctx *ctx, int layout);
 #define PCR_VARIANT_POINT_WINDOWS 2
 int pcr_set_render_variant(pcr_ctx *ctx, int variant);
 
+/* pcr_clear and the cull/LOD prepass of the frame's first render call in ONE launch: equivalent to pcr_clear followed by
+ * what pcr_render_basic (method PCR_METHOD_BASIC) or pcr_render_hqs_depth (PCR_METHOD_HQS) would do first. The render call
+ * that follows skips its prepass if it is given the same parameters and the loaded batches have not changed; otherwise it
+ * runs its own, so calling this is never wrong, only sometimes useless. The frame loop of the adapters uses it where the
+ * reference clears (huffman_hqs.h:266-270 / huffman_mem_iter_cuda.h:250-252). */
+#define PCR_METHOD_BASIC 0
+#define PCR_METHOD_HQS 1
+int pcr_frame_begin(pcr_ctx *ctx, const pcr_render_params *params, int method);
+
 /* Multi-GPU merges through a library that only has a SIGNED 64-bit MIN (RCCL as torch.distributed exposes it): with
  * on = 1, pcr_clear writes INT64_MAX (0x7FFF...F) into empty pixels instead of the reference's all-ones word. Every key a
  * point can produce has a clear top bit (the depth half is the bit pattern of a positive float), so the kernels' unsigned

@@ -69,6 +69,11 @@ struct pcr_ctx {
     int64_t batches_resident = 0;
     int64_t last_frame_batches = 0;
     uint64_t empty_key = ~0ull;                 // what pcr_clear writes (pcr_set_int64_mergeable)
+    // pcr_frame_begin ran the prepass of the next render call already, for exactly these inputs
+    bool prepass_ready = false;
+    pcr_render_params prepass_params{};
+    int prepass_variant_hqs = 0, prepass_win_capacity = 0;
+    int64_t prepass_batches = 0;
     static constexpr int FENCES = 8;
     hipEvent_t fence[FENCES] = {};              // pcr_fence_record / pcr_fence_wait: device-scope ordering between streams
     int64_t visible_batches() const { return async_upload ? batches_resident : batches_loaded; }
@@ -141,7 +146,7 @@ void free_stream_buffers(pcr_ctx *c)
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); c->transcoded = 0;
-    c->stream_open = false; c->batches_loaded = c->points_loaded = 0;
+    c->stream_open = false; c->batches_loaded = c->points_loaded = 0; c->prepass_ready = false;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
 
@@ -231,8 +236,13 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
     a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
-    c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
-    hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
+    const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == a.variant_hqs &&
+                              c->prepass_win_capacity == a.win_capacity && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
+    c->prepass_ready = false;
+    if (!have_prepass) {
+        c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
+        hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
+    }
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
     if (timed) HIP_TRY(c, hipEventRecord(c->kt_begin[slot], c->stream));
@@ -640,6 +650,30 @@ int pcr_clear(pcr_ctx *c)
     hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, c->stream, c->fb, rg, ba, c->fb_elems, c->empty_key);
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
+    return PCR_OK;
+}
+
+int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (method != PCR_METHOD_BASIC && method != PCR_METHOD_HQS) return set_err(c, PCR_E_ARG, "unknown method %d", method);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->async_upload) poll_loader(c, false);
+    const int64_t nB = c->visible_batches();
+    if (nB == 0) return pcr_clear(c);
+    uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
+    if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
+    RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
+    a.win_capacity = WIN_PIXELS;                 // first pass of either method (basic / HQS depth)
+    c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
+    hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
+                       (uint32_t)c->stats_partials, c->fb, rg, ba, c->fb_elems, c->empty_key);
+    HIP_TRY(c, hipGetLastError());
+    c->accum_dirty = false;
+    c->prepass_ready = true;
+    c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_capacity = a.win_capacity;
+    c->prepass_batches = nB;
     return PCR_OK;
 }
 

@@ -145,13 +145,15 @@ constexpr int PREPASS_LANES = 8;
 constexpr int PREPASS_BATCHES = PREPASS_THREADS / PREPASS_LANES;     // batches per workgroup
 __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
 
-__global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a)
+__device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t block)
 {
-    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / PREPASS_LANES;
+    const int64_t b = ((int64_t)block * PREPASS_THREADS + threadIdx.x) / PREPASS_LANES;
     pcr_render_stats st = {0, 0, 0, 0};
     if (b < a.s.num_batches) lod_prepass_batch(a, b, (int)(threadIdx.x % PREPASS_LANES), st);   // uniform per 8-lane group
     commit_stats(st, a.stats);
 }
+
+__global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
 
 __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st)
 {
@@ -1037,20 +1039,36 @@ __global__ void __launch_bounds__(256) k_las_resolve(int width, int height, cons
 // CLEAR block (huffman_hqs.h:266-270): fb <- all ones, and RG/BA <- 0 when a colour pass has written them; one launch,
 // 16-byte stores
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty)
+__device__ __forceinline__ void clear_block(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty,
+                                            uint32_t block, uint32_t blocks)
 {
-    const size_t pairs = n / 2, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t pairs = n / 2, stride = (size_t)blocks * blockDim.x;
     const ulonglong2 ones = make_ulonglong2(empty, empty), zero = make_ulonglong2(0ull, 0ull);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+    for (size_t i = (size_t)block * blockDim.x + threadIdx.x; i < pairs; i += stride) {
         reinterpret_cast<ulonglong2 *>(fb)[i] = ones;
         if (rg) reinterpret_cast<ulonglong2 *>(rg)[i] = zero;
         if (ba) reinterpret_cast<ulonglong2 *>(ba)[i] = zero;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((n & 1) && block == 0 && threadIdx.x == 0) {
         fb[n - 1] = empty;
         if (rg) rg[n - 1] = 0;
         if (ba) ba[n - 1] = 0;
     }
+}
+
+__global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty)
+{
+    clear_block(fb, rg, ba, n, empty, blockIdx.x, gridDim.x);
+}
+
+// CLEAR and the prepass of the frame's first pass in one launch (pcr_frame_begin): the first `prepass_blocks` workgroups
+// do the cull/LOD work (it touches no framebuffer), the others fill. Saves the prepass's 5 us and a launch gap per frame.
+static_assert(PREPASS_THREADS == 256, "k_frame_begin runs both bodies with 256 threads");
+__global__ void __launch_bounds__(256) k_frame_begin(RenderArgs a, uint32_t prepass_blocks, uint64_t *fb, uint64_t *rg,
+                                                     uint64_t *ba, size_t n, uint64_t empty)
+{
+    if (blockIdx.x < prepass_blocks) lod_prepass_block(a, blockIdx.x);
+    else clear_block(fb, rg, ba, n, empty, blockIdx.x - prepass_blocks, gridDim.x - prepass_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -313,7 +313,7 @@ struct HuffmanMemIter : HuffmanMethodBase {
         las->process(r);
         if (las->numPointsLoaded == 0) return;
         lastParams = r->params();
-        r->check(pcr_clear(r->ctx), "pcr_clear");
+        r->check(pcr_frame_begin(r->ctx, &lastParams, PCR_METHOD_BASIC), "pcr_frame_begin");   // CLEAR + cull/LOD prepass
         r->check(pcr_render_basic(r->ctx, &lastParams), "pcr_render_basic");
         r->check(pcr_resolve_basic(r->ctx, &lastParams), "pcr_resolve_basic");
     }
@@ -330,7 +330,7 @@ struct HuffmanHQS : HuffmanMethodBase {
         las->process(r);
         if (las->numPointsLoaded == 0) return;
         lastParams = r->params();
-        r->check(pcr_clear(r->ctx), "pcr_clear");
+        r->check(pcr_frame_begin(r->ctx, &lastParams, PCR_METHOD_HQS), "pcr_frame_begin");
         r->check(pcr_render_hqs_depth(r->ctx, &lastParams), "pcr_render_hqs_depth");
         r->check(pcr_render_hqs_color(r->ctx, &lastParams), "pcr_render_hqs_color");
         if (Debug::saveDepthMap) {                          // huffman_hqs.h:217-237

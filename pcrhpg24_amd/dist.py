@@ -147,7 +147,7 @@ class DeviceFrame:
 def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None, merge: str = "reduce"):
     """One frame of the basic method on this rank's shard + the merge, all on one stream. Enqueue only.
     merge="reduce": the finished frame (and its resolve) live on rank 0; "allreduce": on every rank."""
-    ctx.clear()
+    ctx.frame_begin(params)
     ctx.render_basic(params)
     final = True
     if frame is not None:
@@ -160,7 +160,7 @@ def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: 
 
 
 def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None, merge: str = "reduce"):
-    ctx.clear()
+    ctx.frame_begin(params, hqs=True)
     ctx.render_hqs_depth(params)
     if frame is not None:
         frame.allreduce_min(group)          # global depth before the 1 % test: every rank needs it
@@ -198,7 +198,7 @@ class PipelinedBasicRenderer:
         cs, ms = self.compute.cuda_stream, self.comm.cuda_stream
         self.ctx.fence_wait(2 + i, cs)                 # this framebuffer's previous merge + resolve are done
         f.bind(self.compute)
-        self.ctx.clear()
+        self.ctx.frame_begin(params)
         self.ctx.render_basic(params)
         self.ctx.fence_record(i, cs)
         self.ctx.fence_wait(i, ms)

@@ -353,6 +353,10 @@ class Context:
     def clear(self):
         self._chk(self.lib.pcr_clear(self.h), "pcr_clear")
 
+    def frame_begin(self, p: RenderParams, hqs: bool = False):
+        """pcr_clear + the prepass of the render call that follows, in one launch (pcr_hip.h)."""
+        self._chk(self.lib.pcr_frame_begin(self.h, C.byref(p), 1 if hqs else 0), "pcr_frame_begin")
+
     def render_basic(self, p: RenderParams):
         self._chk(self.lib.pcr_render_basic(self.h, C.byref(p)), "pcr_render_basic")
 
@@ -638,7 +642,7 @@ class HuffmanMemIter(_HuffmanMethod):
             return
         p = renderer.render_params()
         ctx = renderer.ctx
-        ctx.clear()                   # CLEAR (of the previous frame)
+        ctx.frame_begin(p)            # CLEAR (of the previous frame) + the cull/LOD prepass, one launch
         ctx.render_basic(p)           # RENDER
         ctx.resolve_basic(p)          # RESOLVE
         self.last_params = p
@@ -655,7 +659,7 @@ class HuffmanHQS(_HuffmanMethod):
             return
         p = renderer.render_params()
         ctx = renderer.ctx
-        ctx.clear()
+        ctx.frame_begin(p, hqs=True)
         ctx.render_hqs_depth(p)
         ctx.render_hqs_color(p)
         ctx.resolve_hqs(p)

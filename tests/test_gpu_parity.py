@@ -312,3 +312,37 @@ def test_async_loader_frames_draw_what_has_arrived(renderer):
     finally:
         ctx.set_async_upload(False)
         ctx.stream_unload()
+
+
+def test_frame_begin_equals_clear_then_prepass(renderer, stream2m):
+    """pcr_frame_begin = pcr_clear + the prepass of the next render call in one launch: same frames and statistics; a
+    render call with other parameters, another method or after a plain pcr_clear runs its own prepass."""
+    nb, of = stream2m
+    _load(renderer, nb)
+    ctx = renderer.ctx
+    cams = scenes.cameras(W, H)
+    p = scenes.with_flags(cams["overview"], lod_percent=100, cull=0)
+    q = scenes.with_flags(cams["closeup"], lod_percent=10, cull=1)
+    for first, second in ((p, p), (p, q), (q, q)):
+        ctx.render_basic(first)                         # leaves a dirty framebuffer behind
+        ctx.frame_begin(first)
+        ctx.render_basic(second)                        # second != first: the prepared prepass must not be used
+        ofb, ost = of.render_basic(second)
+        assert ctx.stats() == ost
+        assert np.array_equal(ctx.read_framebuffer(full=True), ofb)
+    # HQS: the depth pass takes the prepared prepass, the colour pass (other window size) runs its own
+    ctx.frame_begin(q, hqs=True)
+    ctx.render_hqs_depth(q)
+    hfb, hst = of.render_hqs_depth(q)
+    assert ctx.stats() == hst
+    assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
+    ctx.render_hqs_color(q)
+    org, oba, _ = of.render_hqs_color(q, hfb)
+    rg, ba = ctx.read_accum(full=True)
+    assert np.array_equal(rg, org) and np.array_equal(ba, oba)
+    # prepared for basic, used by HQS depth (other LOD expression): must be recomputed
+    ctx.frame_begin(q, hqs=False)
+    ctx.render_hqs_depth(q)
+    assert ctx.stats() == hst
+    assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
+    _check_basic(ctx, of, p)
