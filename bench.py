@@ -246,6 +246,7 @@ def main():
         frame.release()
     ctx.close()
     if use_dist:
+        dist.barrier()              # rank 0 was busy measuring and printing: leave together
         dist.destroy_process_group()
 
 
