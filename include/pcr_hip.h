@@ -203,8 +203,8 @@ int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
 int pcr_measure_hbm(pcr_ctx *ctx, size_t bytes, int reps, float *read_gbps, float *copy_gbps);
 
 /* Per-launch duration of the dominant kernel: with every = n > 0, every n-th pcr_render_* call brackets its
- * decode+rasterize kernel (not the prepass) with a HIP event pair on the stream it is launched on (an event pair costs
- * ~5 us of stream time, hence the stride); every = 0 switches it off. pcr_kernel_timing_read synchronises and returns
+ * decode+rasterize kernel (not the prepass) with a HIP event pair (device-scope release) on the stream it is launched on
+ * (an event pair still costs stream time, hence the stride); every = 0 switches it off. pcr_kernel_timing_read synchronises and returns
  * the average over the most recent bracketed launches (at most 64) since enabling, and how many those were. */
 int pcr_kernel_timing_enable(pcr_ctx *ctx, int every);
 int pcr_kernel_timing_read(pcr_ctx *ctx, float *avg_ms, int *launches);

@@ -997,12 +997,12 @@ int pcr_measure_hbm(pcr_ctx *c, size_t bytes, int reps, float *read_gbps, float 
 int pcr_kernel_timing_enable(pcr_ctx *c, int every)
 {
     if (!c || every < 0) return PCR_E_ARG;
-    const int on = every;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (on && !c->kt_begin[0])
+    if (every > 0)
         for (int i = 0; i < pcr_ctx::KT_PAIRS; ++i) {
-            HIP_TRY(c, hipEventCreate(&c->kt_begin[i]));
-            HIP_TRY(c, hipEventCreate(&c->kt_end[i]));
+            // device-scope release: the default system-scope one writes the L2 back around the kernel being timed
+            if (!c->kt_begin[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->kt_begin[i], hipEventReleaseToDevice));
+            if (!c->kt_end[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->kt_end[i], hipEventReleaseToDevice));
         }
     c->kt_every = every;
     c->kt_launches = 0;
