@@ -8,9 +8,9 @@
 Workload (BASELINE.json configs[1]): 1e8 synthetic Morton-sorted points, per-batch Huffman-compressed
 (1526 batches), 1920x1080, basic {depth,colour} atomicMin raster, LOD% = 100 and frustum culling off so
 every point is decoded and rasterized. For N > 1 the scene grows to N x 1e8 points (weak
-scaling), chunks are sharded contiguously over the ranks and every step ends with the RCCL min-merge of
-the partial framebuffers (reduce to rank 0, where the frame is resolved; --merge allreduce keeps it everywhere).
-
+scaling), chunks are sharded contiguously over the ranks and every step ends with the merge of the partial
+framebuffers over RCCL: by default an all-to-all of 1/N slices, a local min + resolve of the slice each rank owns and an
+all-gather of the image (--merge reduce: one min-reduce of the whole frame to rank 0, resolved there; --merge allreduce).
 A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM.
 Prints ONE JSON line on rank 0.
 """
@@ -41,8 +41,9 @@ def parse_args():
     ap.add_argument("--lod", type=int, default=100, help="LOD percent (uPointFormat); 100 = all 64 points per chain")
     ap.add_argument("--cull", type=int, default=0)
     ap.add_argument("--camera", choices=["overview", "closeup"], default="overview")
-    ap.add_argument("--merge", choices=["reduce", "allreduce"], default="reduce",
-                    help="multi-GPU exchange: min-reduce the partial framebuffers to rank 0 (the display rank) or all-reduce them")
+    ap.add_argument("--merge", choices=["reduce", "allreduce", "a2a"], default="a2a",
+                    help="multi-GPU exchange of the basic method: min-reduce the partial framebuffers to rank 0 (the display "
+                         "rank), all-reduce them, or all-to-all slices + local min/resolve + all-gather of the image")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -124,7 +125,8 @@ def main():
         step = lambda: pipe.step(p)
     else:
         if use_dist:
-            frame = pdist.DeviceFrame(ctx, args.width, args.height, dev)
+            frame = pdist.SlicedFrame(ctx, args.width, args.height, dev, world) if (args.merge == "a2a" and args.method == "basic") \
+                else pdist.DeviceFrame(ctx, args.width, args.height, dev)
             frame.bind()
             ctx.clear()
         step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world, merge=args.merge)) if args.method == "basic" else \
@@ -219,6 +221,11 @@ def main():
             ctx.clear(); (ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth)(p)
             parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb))
 
+    if args.method == "hqs":
+        merge_desc = "min all-reduce of the depth + sum %s of the colour sums" % ("all-reduce" if args.merge == "allreduce" else "reduce to rank 0")
+    else:
+        merge_desc = {"reduce": "min reduce to rank 0", "allreduce": "min all-reduce",
+                      "a2a": "all-to-all of frame slices + local min/resolve + all-gather of the image"}[args.merge]
     if rank == 0:
         out = {
             "metric": "Mpoints/s decoded+rasterized @%dx%d" % (args.width, args.height),
@@ -231,7 +238,7 @@ def main():
                        "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
-                       "parallelism": ("batch-sharded x%d + RCCL min %s%s" % (world, "reduce to rank 0" if args.merge == "reduce" else "all-reduce", " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
+                       "parallelism": ("batch-sharded x%d + RCCL %s%s" % (world, merge_desc, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2),
                        "first_frame_ms": round(first_frame_ms, 3)},
             "roofline": roofline,

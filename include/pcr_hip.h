@@ -141,6 +141,15 @@ int   pcr_flip_sign(pcr_ctx *ctx);
 /* ---- measurement ---------------------------------------------------------------------------------
  * HIP events on the context's stream: begin/end bracket any sequence of enqueued calls;
  * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
+/* All-to-all form of the multi-GPU merge (pcrhpg24_amd/dist.py, merge="a2a"): the frame is cut into N contiguous slices
+ * of slice_elems words; after an all-to-all a rank holds everyone's copy of the slice it owns, back to back.
+ * pcr_merge_min_slices leaves their element-wise min in the first slice; pcr_resolve_basic_range resolves `count` pixels of
+ * a framebuffer range as pcr_resolve_basic does (the basic resolve depends on the word only, resolve.cu:149-191) into
+ * `rgba`, which an all-gather then assembles into the image. Both work on device pointers the caller owns and enqueue
+ * on the context's stream. */
+int pcr_merge_min_slices(pcr_ctx *ctx, void *slices, int nslices, size_t slice_elems);
+int pcr_resolve_basic_range(pcr_ctx *ctx, const pcr_render_params *params, const void *fb, size_t count, void *rgba);
+
 /* Ordering between two streams of the context's device without the system-scope release a default HIP event carries
  * (which writes the L2 back: the 16.6 MB framebuffer the next kernel is about to read). slot in [0, 8). A frame rendered
  * on one stream and merged on another uses two of these per frame. stream NULL = the context's stream. */

@@ -892,6 +892,29 @@ int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
     return PCR_OK;
 }
 
+int pcr_merge_min_slices(pcr_ctx *c, void *slices, int nslices, size_t slice_elems)
+{
+    if (!c || !slices || nslices < 1 || slice_elems == 0) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (nslices > 1) {
+        // few workgroups: this runs next to a render, whose 1024-thread workgroups wait for whole CUs' worth of wave slots
+        hipLaunchKernelGGL(k_merge_min_slices, dim3(128), dim3(256), 0, c->stream, (uint64_t *)slices, nslices, slice_elems);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return PCR_OK;
+}
+
+int pcr_resolve_basic_range(pcr_ctx *c, const pcr_render_params *p, const void *fb, size_t count, void *rgba)
+{
+    if (!c || !p || !fb || !rgba) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (count == 0) return PCR_OK;
+    hipLaunchKernelGGL(k_resolve_range, dim3(128), dim3(256), 0, c->stream, p->show_num_points, p->colorize_chunks,
+                       (const uint64_t *)fb, count, (uint32_t *)rgba);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
 int pcr_fence_record(pcr_ctx *c, int slot, void *hip_stream)
 {
     if (!c || slot < 0 || slot >= pcr_ctx::FENCES) return PCR_E_ARG;

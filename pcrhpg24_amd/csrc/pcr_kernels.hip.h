@@ -1097,6 +1097,39 @@ __global__ void __launch_bounds__(256) k_hbm_copy(const hbm_vec4 *src, hbm_vec4 
 // ------------------------------------------------------------------------------------------------
 // resolve (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
 // ------------------------------------------------------------------------------------------------
+// The basic method's resolve depends on the framebuffer word only, not on the pixel's position: a contiguous range of
+// pixels (a slice of the frame a rank owns after the all-to-all merge) resolves on its own. Same arithmetic as k_resolve<false>.
+__global__ void __launch_bounds__(256) k_resolve_range(int show_num_points, int colorize_chunks, const uint64_t *fb,
+                                                       size_t count, uint32_t *rgba)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t id = (uint32_t)fb[i];
+        uint32_t color = PCR_BACKGROUND_COLOR;
+        if (id < 0xFFFFFFFFu) {
+            if (show_num_points) {
+                const uint32_t shade = (uint32_t)(((double)(float)(int)id / 64.0) * 255.0);
+                color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+            } else if (colorize_chunks) {
+                color = id * 1234567u;
+            } else {
+                color = id;
+            }
+        }
+        rgba[i] = color;
+    }
+}
+
+// slices[0 .. S) <- element-wise min over `ns` slices of S words laid out back to back (what a rank holds after the
+// all-to-all: everyone's copy of the slice of the frame it owns)
+__global__ void __launch_bounds__(256) k_merge_min_slices(uint64_t *slices, int ns, size_t S)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t m = slices[i];
+        for (int r = 1; r < ns; ++r) m = min(m, slices[(size_t)r * S + i]);
+        slices[i] = m;
+    }
+}
+
 template <bool HQS>
 __global__ void __launch_bounds__(256) k_resolve(int show_num_points, int colorize_chunks, int width, int height,
                                                  const uint64_t *fb, const uint64_t *rg, const uint64_t *ba,

@@ -144,13 +144,86 @@ class DeviceFrame:
         self.ctx.set_stream(0)
 
 
-def render_basic_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: int, group=None, merge: str = "reduce"):
+def slice_elems(n: int, world_size: int) -> int:
+    """Words per slice when a frame of n words is cut into world_size slices (even, so every slice stays 16-byte aligned)."""
+    return (-(-n // world_size) + 1) & ~1
+
+
+def a2a_merge(fb, recv, rgba_slice, rgba, world_size: int, min_slices, resolve_range, group=None):
+    """The all-to-all form of the basic method's merge, on torch tensors of either backend (RCCL on the GPU, gloo in the
+    CPU tests). fb: this rank's frame, int64[world_size * S], empty pixels INT64_MAX, padding included. After the call
+    recv[:S] holds the merged slice this rank owns, rgba_slice its resolved pixels and rgba (int32[world_size * S]) the
+    whole image on every rank. Point-to-point xGMI carries 1/N of the frame per link instead of the whole frame around a
+    ring; the element-wise work (min_slices, resolve_range) is the caller's: HIP kernels on the GPU path."""
+    import torch.distributed as dist
+    S = fb.numel() // world_size
+    dist.all_to_all_single(recv, fb, group=group)           # recv[r*S:(r+1)*S] = rank r's copy of my slice
+    min_slices(recv, world_size, S)                         # -> recv[:S]
+    resolve_range(recv, S, rgba_slice)
+    dist.all_gather_into_tensor(rgba, rgba_slice, group=group)
+
+
+class SlicedFrame:
+    """A frame for merge="a2a": torch-owned like DeviceFrame, padded to world_size equal slices, plus the receive buffer
+    and the image tensors of a2a_merge."""
+
+    def __init__(self, ctx, width: int, height: int, device, world_size: int):
+        import torch
+        from ._native import fb_elems
+        self.ctx, self.device, self.world = ctx, device, world_size
+        self.n = fb_elems(width, height)
+        self.S = slice_elems(self.n, world_size)
+        big = torch.iinfo(torch.int64).max
+        self.fb = torch.full((world_size * self.S,), big, dtype=torch.int64, device=device)   # the padding stays empty
+        self.recv = torch.empty(world_size * self.S, dtype=torch.int64, device=device)
+        self.rgba_slice = torch.empty(self.S, dtype=torch.int32, device=device)
+        self.rgba = torch.empty(world_size * self.S, dtype=torch.int32, device=device)
+        self.rg = self.ba = self.acc = None
+
+    def bind(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.ctx.set_stream(s.cuda_stream)
+        self.ctx.use_external_buffers(self.fb.data_ptr(), 0, 0)
+        self.ctx.set_int64_mergeable(True)
+
+    def merge_and_resolve(self, params, group=None):
+        """Enqueue on torch's current stream (which must be the stream the context is bound to)."""
+        ctx = self.ctx
+        a2a_merge(self.fb, self.recv, self.rgba_slice, self.rgba, self.world,
+                  lambda t, ns, S: ctx.merge_min_slices(t.data_ptr(), ns, S),
+                  lambda t, S, out: ctx.resolve_basic_range(params, t.data_ptr(), S, out.data_ptr()), group)
+
+    def image(self):
+        """RGBA8 words of the merged frame (valid on every rank once the stream has drained)."""
+        return self.rgba[:self.n]
+
+    def gather_merged_framebuffer(self, group=None):
+        """u64 words of the merged frame, assembled from the slices the ranks own (tests / dumps; not part of a frame)."""
+        import torch
+        import torch.distributed as dist
+        out = torch.empty_like(self.fb)
+        dist.all_gather_into_tensor(out, self.recv[:self.S].contiguous(), group=group)
+        return out[:self.n]
+
+    def release(self):
+        self.ctx.synchronize()
+        self.ctx.use_external_buffers(0, 0, 0)
+        self.ctx.set_int64_mergeable(False)
+        self.ctx.set_stream(0)
+
+
+def render_basic_sharded(ctx, frame, params, world_size: int, group=None, merge: str = "reduce"):
     """One frame of the basic method on this rank's shard + the merge, all on one stream. Enqueue only.
-    merge="reduce": the finished frame (and its resolve) live on rank 0; "allreduce": on every rank."""
+    merge="reduce": the finished frame (and its resolve) live on rank 0; "allreduce": on every rank; "a2a" (frame is a
+    SlicedFrame): every rank merges and resolves the slice it owns, the image is all-gathered."""
     ctx.frame_begin(params)
     ctx.render_basic(params)
     final = True
     if frame is not None:
+        if merge == "a2a":
+            frame.merge_and_resolve(params, group)
+            return
         if merge == "reduce":
             final = frame.reduce_min(0, group)
         else:
@@ -167,7 +240,7 @@ def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: in
     ctx.render_hqs_color(params)
     final = True
     if frame is not None:
-        if merge == "reduce":
+        if merge in ("reduce", "a2a"):      # the all-to-all form exists for the basic method only
             final = frame.reduce_sum(0, group)
         else:
             frame.allreduce_sum(group)
@@ -190,12 +263,17 @@ class PipelinedBasicRenderer:
         import torch
         import torch.distributed as dist
         self.ctx, self.device, self.group, self.merge = ctx, device, group, merge
-        self.frames = [DeviceFrame(ctx, width, height, device, accum=False), DeviceFrame(ctx, width, height, device, accum=False)]
+        if merge == "a2a":
+            world = dist.get_world_size(group)
+            self.frames = [SlicedFrame(ctx, width, height, device, world), SlicedFrame(ctx, width, height, device, world)]
+        else:
+            self.frames = [DeviceFrame(ctx, width, height, device, accum=False), DeviceFrame(ctx, width, height, device, accum=False)]
         self.compute = torch.cuda.Stream(device)
         self.comm = torch.cuda.Stream(device, priority=-1)   # the collective should not queue behind a frame's 1526 workgroups
         # stream-to-stream ordering goes through the context's device-scope fences (slots 0,1: frame i rendered; 2,3: frame
         # i merged): a default event releases to system scope, i.e. writes the L2 with the framebuffer in it back
-        self.final = merge != "reduce" or dist.get_rank(group) == 0   # does this rank hold (and resolve) merged frames?
+        # does this rank hold (and resolve) whole merged frames? (a2a: every rank resolves its slice on the merge side)
+        self.final = merge == "allreduce" or (merge == "reduce" and dist.get_rank(group) == 0)
         self.params = [None, None]
         self.unresolved = [False, False]
         self.k = 0
@@ -224,7 +302,10 @@ class PipelinedBasicRenderer:
         self.unresolved[i] = True
         self.ctx.fence_wait(i, ms)
         with torch.cuda.stream(self.comm):             # RCCL orders itself against torch's current stream
-            if self.merge == "reduce":
+            if self.merge == "a2a":
+                f.bind(self.comm)                      # its two small kernels sit between the two collectives
+                f.merge_and_resolve(self.params[i], self.group)
+            elif self.merge == "reduce":
                 f.reduce_min(0, self.group)
             else:
                 f.allreduce_min(self.group)

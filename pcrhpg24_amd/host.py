@@ -430,6 +430,12 @@ class Context:
         """Which decode variant draws a stream that has both layouts resident (pcr_hip.h: PCR_VARIANT_*)."""
         self._chk(self.lib.pcr_set_render_variant(self.h, int(variant)), "pcr_set_render_variant")
 
+    def merge_min_slices(self, slices_ptr: int, nslices: int, slice_elems: int) -> None:
+        self._chk(self.lib.pcr_merge_min_slices(self.h, slices_ptr, nslices, slice_elems), "pcr_merge_min_slices")
+
+    def resolve_basic_range(self, p: RenderParams, fb_ptr: int, count: int, rgba_ptr: int) -> None:
+        self._chk(self.lib.pcr_resolve_basic_range(self.h, C.byref(p), fb_ptr, count, rgba_ptr), "pcr_resolve_basic_range")
+
     def fence_record(self, slot: int, hip_stream: int = 0) -> None:
         self._chk(self.lib.pcr_fence_record(self.h, slot, hip_stream), "pcr_fence_record")
 

@@ -137,3 +137,57 @@ def test_sign_flip_min_is_unsigned_min():
     a[:10] = 0xFFFFFFFFFFFFFFFF
     fa, fb = (a ^ pdist.SIGN).view(np.int64), (b ^ pdist.SIGN).view(np.int64)
     assert np.array_equal(np.minimum(fa, fb).view(np.uint64) ^ pdist.SIGN, np.minimum(a, b))
+
+
+def _a2a_worker(rank, world, port, total, out_dir):
+    """The all-to-all form of the merge (pdist.a2a_merge) over gloo: each rank renders its shard with the oracle into an
+    int64-mergeable frame (empty = INT64_MAX), the element-wise steps run as torch/numpy stand-ins for the HIP kernels."""
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        image, _ = P.synth_encode(total, scenes.SEED, nthreads=2)
+        of = oracle.OracleFile(image.view())
+        first, count = pdist.shard_range(of.num_batches, world, rank)
+        cam = scenes.with_flags(scenes.cameras(W, H)["overview"], lod_percent=100)
+        part, _ = of.render_basic(cam, first=first, count=count)
+        n = part.size
+        S = pdist.slice_elems(n, world)
+        big = np.iinfo(np.int64).max
+        fb = torch.full((world * S,), big, dtype=torch.int64)
+        fb[:n] = torch.from_numpy(np.where(part == np.uint64(2 ** 64 - 1), np.uint64(big), part).view(np.int64))
+        recv = torch.empty(world * S, dtype=torch.int64)
+        rgba_slice = torch.empty(S, dtype=torch.int32)
+        rgba = torch.empty(world * S, dtype=torch.int32)
+
+        def min_slices(t, ns, s):
+            t[:s] = t.view(ns, s).min(dim=0).values
+
+        def resolve_range(t, s, out):                      # resolve.cu:149-191, BC1 mode, no debug flags
+            lo = (t[:s].numpy().view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            out[:] = torch.from_numpy(np.where(lo != 0xFFFFFFFF, lo, np.uint32(0x00443322)).view(np.int32))
+
+        pdist.a2a_merge(fb, recv, rgba_slice, rgba, world, min_slices, resolve_range)
+        merged = torch.empty(world * S, dtype=torch.int64)
+        dist.all_gather_into_tensor(merged, recv[:S].contiguous())
+        np.savez(os.path.join(out_dir, f"a2a{rank}.npz"), rgba=rgba[:n].numpy().view(np.uint32), merged=merged[:n].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_to_all_merge_reproduces_single_process_render(tmp_path, world):
+    total = 600_000                         # 10 batches -> 5 + 5 or 4 + 3 + 3; 320x180 (+ padding) is not a multiple of 3 slices
+    mp.spawn(_a2a_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    image, _ = P.synth_encode(total, scenes.SEED, nthreads=2)
+    of = oracle.OracleFile(image.view())
+    cam = scenes.with_flags(scenes.cameras(W, H)["overview"], lod_percent=100)
+    fb, _ = of.render_basic(cam)
+    want_rgba = oracle.resolve_basic(cam, fb)
+    big = np.iinfo(np.int64).max
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"a2a{rank}.npz"))
+        merged = np.where(z["merged"] == big, -1, z["merged"]).view(np.uint64)
+        assert np.array_equal(merged, fb), f"rank {rank}: merged framebuffer"
+        assert np.array_equal(z["rgba"][:want_rgba.size], want_rgba.ravel()), f"rank {rank}: image"

@@ -98,3 +98,65 @@ def test_pipelined_renderer_frames(group, loaded):
         assert np.array_equal(ctx.read_framebuffer(full=True), of.render_basic(seq[-1])[0])
     finally:
         pipe.release()
+
+
+def test_slice_kernels_against_numpy(group, loaded):
+    """pcr_merge_min_slices / pcr_resolve_basic_range on their own: three slices of random keys (empty = INT64_MAX)."""
+    import torch
+    ctx, _ = loaded
+    rng = np.random.default_rng(5)
+    S, ns = 10_002, 3
+    # depth half: any positive float's bits; payload half: small enough for the showNumPoints shade (an int in the reference)
+    keys = (rng.integers(1, 0x7F800000, size=(ns, S), dtype=np.int64) << 32) | rng.integers(0, 2 ** 20, size=(ns, S), dtype=np.int64)
+    keys[rng.random((ns, S)) < 0.4] = np.iinfo(np.int64).max
+    t = torch.from_numpy(keys.reshape(-1).copy()).to(group)
+    ctx.set_stream(torch.cuda.current_stream(group).cuda_stream)
+    try:
+        ctx.merge_min_slices(t.data_ptr(), ns, S)
+        want = keys.min(axis=0)
+        for flags in ({}, {"show_num_points": 1}, {"colorize_chunks": 1}):
+            p = scenes.with_flags(scenes.cameras(W, H)["overview"], **flags)
+            out = torch.empty(S, dtype=torch.int32, device=group)
+            ctx.resolve_basic_range(p, t.data_ptr(), S, out.data_ptr())
+            torch.cuda.synchronize()
+            fbw = np.where(want == np.iinfo(np.int64).max, -1, want).view(np.uint64)
+            padded = np.full(W * (H + 1) + 1, 2 ** 64 - 1, dtype=np.uint64)
+            m = min(S, W * H)
+            padded[:m] = fbw[:m]
+            ref = oracle.resolve_basic(p, padded).ravel()[:m]
+            assert np.array_equal(out.cpu().numpy().view(np.uint32)[:m], ref), flags
+        assert np.array_equal(t.cpu().numpy()[:S], want)
+    finally:
+        ctx.set_stream(0)
+
+
+def test_all_to_all_form_on_a_single_rank_group(group, loaded):
+    import torch
+    ctx, of = loaded
+    p = scenes.with_flags(scenes.cameras(W, H)["closeup"], lod_percent=100, cull=1)
+    frame = pdist.SlicedFrame(ctx, W, H, group, 1)
+    try:
+        frame.bind()
+        pdist.render_basic_sharded(ctx, frame, p, 1, merge="a2a")
+        torch.cuda.synchronize()
+        ofb, _ = of.render_basic(p)
+        merged = frame.gather_merged_framebuffer().cpu().numpy()
+        assert np.array_equal(np.where(merged == np.iinfo(np.int64).max, -1, merged).view(np.uint64), ofb)
+        want = oracle.resolve_basic(p, ofb).ravel()
+        assert np.array_equal(frame.image().cpu().numpy().view(np.uint32)[:want.size], want)
+    finally:
+        frame.release()
+    pipe = pdist.PipelinedBasicRenderer(ctx, W, H, group, merge="a2a")
+    try:
+        cams = scenes.cameras(W, H)
+        seq = [scenes.with_flags(cams[name], lod_percent=lod, cull=cull) for name, lod, cull in (("overview", 100, 0), ("closeup", 10, 1), ("inside", 100, 1))]
+        for q in seq:
+            pipe.step(q)
+        pipe.finish()
+        want = oracle.resolve_basic(seq[-1], of.render_basic(seq[-1])[0]).ravel()
+        assert np.array_equal(pipe.last_frame().image().cpu().numpy().view(np.uint32)[:want.size], want)
+        # and the frame before it is still intact in the other buffer
+        want = oracle.resolve_basic(seq[-2], of.render_basic(seq[-2])[0]).ravel()
+        assert np.array_equal(pipe.frames[pipe.k & 1].image().cpu().numpy().view(np.uint32)[:want.size], want)
+    finally:
+        pipe.release()
