@@ -191,3 +191,28 @@ def test_pad_tails_stream(ctx):
         p = scenes.with_flags(scenes.cameras(640, 360)[cam], lod_percent=100, cull=0)
         stt = check_all(ctx, of, p)
         assert stt["points_iterated"] == of.num_batches * 65536
+
+
+def test_async_loader_with_shard_tail(ctx):
+    """A shard loaded through the loader stream (pcr_set_async_upload) and closed with pcr_upload_tail draws the same
+    frame as the oracle's render of that batch range of the whole file (the last batch is re-walked with the follower's words)."""
+    image, _ = scenes.synth_stream(600_000)
+    f = P.HuffmanFile(image)
+    of = oracle.OracleFile(image.view())
+    w, h = 320, 180
+    first, count = 0, f.numBatches // 2
+    ctx.set_image_size(w, h)
+    ctx.stream_begin(f.header(first, count), first)
+    ctx.set_async_upload(True)
+    try:
+        for b0 in range(0, count, 2):
+            ctx.upload_batches(b0, [f.blob(first + b) for b in range(b0, min(b0 + 2, count))])
+        ctx.upload_tail(*f.head_words(first + count))
+        assert ctx.batches_resident == count
+        p = scenes.with_flags(P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h), lod_percent=100)
+        ctx.clear(); ctx.render_basic(p)
+        ofb, ost = of.render_basic(p, first=first, count=count)
+        assert ctx.stats() == ost
+        assert np.array_equal(ctx.read_framebuffer(full=True), ofb)
+    finally:
+        ctx.set_async_upload(False)
