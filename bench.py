@@ -217,6 +217,13 @@ def main():
                         "cores": nthreads if args.method == "basic" else 1, "kind": "port",
                         "sample": "%d of %d batches (%d points) of the same stream and camera, oracle/pcr_oracle.c, %.1f s wall"
                                   % (sample, nb, ost["points_iterated"], cpu_s)}
+        if args.method == "basic" and nthreads > 1:       # single core as well, on a bounded part of the same stream
+            one = max(1, min(nb, 64))
+            t0 = time.perf_counter()
+            _, ost1 = of.render_basic(p.copy(), first=0, count=one, nthreads=1)
+            s1 = time.perf_counter() - t0
+            cpu_baseline["single_core"] = {"value": round(ost1["points_iterated"] / s1 / 1e6, 3), "unit": "Mpoints/s",
+                                           "sample": "first %d batches (%d points), %.1f s wall" % (one, ost1["points_iterated"], s1)}
         if sample == nb:        # same inputs end to end: compare the whole framebuffer, bit for bit
             ctx.clear(); (ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth)(p)
             parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb))
