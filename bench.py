@@ -214,7 +214,7 @@ def main():
             of.render_hqs_depth(q, first=0, count=sample)
         cpu_s = time.perf_counter() - t0
         cpu_baseline = {"value": round(ost["points_iterated"] / cpu_s / 1e6, 3), "unit": "Mpoints/s",
-                        "cores": nthreads if args.method == "basic" else 1, "kind": "port",
+                        "cores": nthreads if args.method == "basic" else 1, "host_cores": os.cpu_count(), "kind": "port",
                         "sample": "%d of %d batches (%d points) of the same stream and camera, oracle/pcr_oracle.c, %.1f s wall"
                                   % (sample, nb, ost["points_iterated"], cpu_s)}
         if args.method == "basic" and nthreads > 1:       # single core as well, on a bounded part of the same stream
