@@ -41,3 +41,15 @@ def test_numbers_are_consistent(line):
     assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     assert line["parity_full_size"] is True
     assert r["kernel_ms"] <= line["ms_per_step"]
+
+
+def test_measured_ceiling_and_traffic_are_reported(line):
+    r = line["roofline"]
+    m = r["peak_measured"]
+    assert m["unit"] == "GB/s" and 3000.0 < m["stream_copy"] < m["stream_read"] <= r["peak"]
+    assert abs(m["frac_of_read"] - r["achieved"] / m["stream_read"]) < 1e-3
+    # the point-window layout reads more than the compressed bytes on purpose; it is reported, not hidden
+    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes"]
+    assert r["kernel_launches_timed"] >= 32
+    one = line["cpu_baseline"]["single_core"]
+    assert 0 < one["value"] < line["cpu_baseline"]["value"]
