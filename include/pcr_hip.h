@@ -167,7 +167,7 @@ int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
 #define PCR_LAYOUT_POINT_WINDOWS 1
 int pcr_set_stream_layout(pcr_ctx *ctx, int layout);
 /* A stream loaded with PCR_LAYOUT_POINT_WINDOWS keeps the packed words too, so either decode variant can draw a frame.
- * AUTO (default): the point-window variant while the image has at most 4608 pixels (one LDS framebuffer window) per loaded
+ * AUTO (default): the point-window variant while the image has at most 4096 pixels (one LDS framebuffer window) per loaded
  * batch, the packed-words variant beyond that, where the frame is bound by global framebuffer traffic and the smaller
  * stream wins. WORDS / POINT_WINDOWS force one (the latter only where the windows are resident). Results are identical. */
 #define PCR_VARIANT_AUTO 0

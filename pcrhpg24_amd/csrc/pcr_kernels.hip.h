@@ -30,10 +30,10 @@ enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2 };
 // k_render's LDS plan (76 KiB per 1024-thread workgroup -> two workgroups per CU)
 constexpr int CHUNK_WORDS    = 64;               // stream staging granule per cluster: 32 lanes x 2 words (8-byte loads)
 constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                                   -> 16 KiB
-constexpr int ESC_POOL_WORDS = 6144;             // escape words of the whole batch, pooled        -> 24 KiB
+constexpr int ESC_POOL_WORDS = 7168;             // escape words of the whole batch, pooled        -> 28 KiB
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
-constexpr int WIN_PIXELS     = 4608;             // u64 framebuffer window of the batch's rectangle -> 36 KiB
-constexpr int WIN_PIXELS_HQS = 1843;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 36 KiB
+constexpr int WIN_PIXELS     = 4096;             // u64 framebuffer window of the batch's rectangle -> 32 KiB
+constexpr int WIN_PIXELS_HQS = 1638;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 32 KiB
 // Lane-major copy of the word stream (k_transcode): row r holds the r-th word each of the batch's 1024 chains consumes.
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
@@ -251,9 +251,9 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
 // Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
 //   s_table  16 KiB  decoder table packed to one dword per key: slow<<31 | (value + 2^20)<<10 | wide<<9 | escape<<8 | len
 //                    (an in-table value outside +-2^20 is flagged `wide` and re-read from global memory)
-//   s_esc    24 KiB  the escape ("separate") words of the batch, bulk-loaded coalesced up front (batches with
-//                    more than ESC_POOL_WORDS escapes read them from global memory instead)
-//   s_win    36 KiB  the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
+//   s_esc    28 KiB  the escape ("separate") words of the batch, bulk-loaded coalesced up front (batches with
+//                    more than ESC_POOL_WORDS escapes read the ones past the pool from global memory)
+//   s_win    32 KiB  the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
 //                    and the atomicMin of every point that lands inside run on LDS (ds_read_b64 / ds_min_u64);
 //                    at the end the rectangle is merged into the global framebuffer with one row-coalesced
 //                    atomicMin per improved pixel. min is associative, so the result is the same u64 per pixel;
@@ -298,6 +298,16 @@ __device__ __forceinline__ void window_row_col(uint32_t i, uint32_t ww, float in
     if (r < 0) { --y; r += (int32_t)ww; }
     else if (r >= (int32_t)ww) { ++y; r -= (int32_t)ww; }
     x = (uint32_t)r;
+}
+
+// How many of a batch's escape words k_render keeps in LDS: all of them plus ESC_SLACK words that follow them in memory
+// (the reference's tail over-reads), or as many as the pool holds. A batch with more than that is flagged
+// (BF_GENERIC_SLOW_PATH) and its chains check every escape index: the first ESC_POOL_WORDS still come from LDS, only
+// the rest from global memory. (Pooling none of an oversized batch's escapes made that batch twice as slow, and a few
+// such batches made the whole launch 14 % longer: they finish last on their CUs.)
+__device__ __forceinline__ uint32_t esc_pool_words(uint32_t esc_total)
+{
+    return min(esc_total + (uint32_t)ESC_SLACK, (uint32_t)ESC_POOL_WORDS);
 }
 
 // One packed dword per table key (layout above): value and length of render.cu:435-439 in a single LDS read.
@@ -404,7 +414,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     // may k_render read this batch's escapes from its LDS pool unchecked? (same pool rule as there)
     const int32_t *ssz = s.separate_sizes + (size_t)b * 1024;
     const uint32_t esc_total = (uint32_t)ssz[1023];
-    const uint32_t esc_lds = esc_total + ESC_SLACK <= (uint32_t)ESC_POOL_WORDS ? esc_total + ESC_SLACK : 0u;
+    const uint32_t esc_lds = esc_pool_words(esc_total);
     const uint32_t sp0 = tid ? (uint32_t)ssz[tid - 1] : 0u;
     if (nesc && sp0 + nesc > esc_lds) generic = true;
     const int any = __syncthreads_or(generic ? 1 : 0);
@@ -466,7 +476,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // The pool also takes ESC_SLACK words that FOLLOW the batch's own escapes in memory, so that the reference's
     // tail over-reads find in LDS what they would find in global memory; reads beyond even that, and
     // batches that do not fit, go to global memory (slow variant of the decode step).
-    const uint32_t esc_lds = esc_total + ESC_SLACK <= (uint32_t)ESC_POOL_WORDS ? esc_total + ESC_SLACK : 0u;
+    const uint32_t esc_lds = esc_pool_words(esc_total);
     {   // all loads of a thread in flight together (ESC_POOL_WORDS / 1024 = 6 per thread)
         int32_t v[ESC_POOL_WORDS / PCR_WORKGROUP_SIZE];
 #pragma unroll
@@ -483,7 +493,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t wpix = ww * wh;                          // 0: no window for this batch
     const uint32_t W = (uint32_t)a.p.width;
     const float inv_ww = 1.0f / (float)max(ww, 1u);
-    // colour pass layout of the same 36 KiB: sums in the framebuffer's own packed format + the depth to test against
+    // colour pass layout of the same 32 KiB: sums in the framebuffer's own packed format + the depth to test against
     unsigned long long *const s_rg = s_win, *const s_ba = s_win + WIN_PIXELS_HQS;
     uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * WIN_PIXELS_HQS);
     {   // snapshot of the rectangle, all loads of a thread in flight together (a stale value is a valid start)
