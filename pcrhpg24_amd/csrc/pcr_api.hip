@@ -72,7 +72,7 @@ struct pcr_ctx {
     // pcr_frame_begin ran the prepass of the next render call already, for exactly these inputs
     bool prepass_ready = false;
     pcr_render_params prepass_params{};
-    int prepass_variant_hqs = 0, prepass_win_capacity = 0;
+    int prepass_variant_hqs = 0, prepass_win_pixel_bytes = 0;
     int64_t prepass_batches = 0;
     static constexpr int FENCES = 8;
     hipEvent_t fence[FENCES] = {};              // pcr_fence_record / pcr_fence_wait: device-scope ordering between streams
@@ -234,10 +234,10 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     c->last_frame_batches = nB;
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
-    a.win_capacity = MODE == MODE_HQS_COLOR ? WIN_PIXELS_HQS : WIN_PIXELS;
+    a.win_pixel_bytes = MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == a.variant_hqs &&
-                              c->prepass_win_capacity == a.win_capacity && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
+                              c->prepass_win_pixel_bytes == a.win_pixel_bytes && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
     c->prepass_ready = false;
     if (!have_prepass) {
         c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
@@ -665,14 +665,14 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
-    a.win_capacity = WIN_PIXELS;                 // first pass of either method (basic / HQS depth)
+    a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
                        (uint32_t)c->stats_partials, c->fb, rg, ba, c->fb_elems, c->empty_key);
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     c->prepass_ready = true;
-    c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_capacity = a.win_capacity;
+    c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_pixel_bytes = a.win_pixel_bytes;
     c->prepass_batches = nB;
     return PCR_OK;
 }

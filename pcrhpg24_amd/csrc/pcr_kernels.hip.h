@@ -30,10 +30,34 @@ enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2 };
 // k_render's LDS plan (76 KiB per 1024-thread workgroup -> two workgroups per CU)
 constexpr int CHUNK_WORDS    = 64;               // stream staging granule per cluster: 32 lanes x 2 words (8-byte loads)
 constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                                   -> 16 KiB
-constexpr int ESC_POOL_WORDS = 7168;             // escape words of the whole batch, pooled        -> 28 KiB
+// 60 KiB of k_render's LDS are shared between the batch's escape words and its framebuffer window, divided per batch: the
+// pool takes what the batch's escapes need (up to ESC_POOL_WORDS, which leaves 1024 window pixels), the window gets the rest.
+// The benchmark stream's batches have 3831..7037 escape words: windows of 4090..5760 pixels. A fixed 24 + 36 KiB split put 6 %
+// of those batches on the checked escape path, 1.5x slower each, and they finished last on their CUs (+17 % per launch).
+constexpr int DYN_LDS_BYTES  = 60 * 1024;
+constexpr int ESC_POOL_WORDS = 13312;            // most escape words of a batch the pool ever holds -> 52 KiB
+constexpr int ESC_POOL_EAGER = 7168;             // words every workgroup requests before it knows the batch's count
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
-constexpr int WIN_PIXELS     = 4096;             // u64 framebuffer window of the batch's rectangle -> 32 KiB
-constexpr int WIN_PIXELS_HQS = 1638;             // colour pass: {RG u64, BA u64, depth u32} per pixel  -> 32 KiB
+constexpr int WIN_PIXELS     = 4096;             // nominal window (a batch with 7104 escape words); the 10-10-10 kernel's fixed one
+constexpr int WIN_PIXEL_BYTES     = 8;           // basic / HQS depth: the u64 framebuffer word
+constexpr int WIN_PIXEL_BYTES_HQS = 20;          // HQS colour: {RG u64, BA u64, depth u32}
+constexpr int WIN_PIXELS_MAX = DYN_LDS_BYTES / WIN_PIXEL_BYTES;
+// How many of a batch's escape words k_render keeps in LDS: all of them plus ESC_SLACK words that follow them in memory
+// (the reference's tail over-reads, SURVEY B.4), or as many as the pool holds. A batch with more than that is flagged
+// (BF_GENERIC_SLOW_PATH) and its chains check every escape index: the first ESC_POOL_WORDS still come from LDS, only
+// the rest from global memory. (Pooling none of an oversized batch's escapes made that batch twice as slow, and a few
+// such batches made the whole launch 14 % longer: they finish last on their CUs.)
+__device__ __forceinline__ uint32_t esc_pool_words(uint32_t esc_total)
+{
+    return min(esc_total + (uint32_t)ESC_SLACK, (uint32_t)ESC_POOL_WORDS);
+}
+__device__ __forceinline__ uint32_t esc_pool_bytes(uint32_t pool_words) { return (pool_words * 4u + 15u) & ~15u; }
+// pixels the batch's LDS window can hold next to its escape pool
+__device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_bytes)
+{
+    return (int)((DYN_LDS_BYTES - esc_pool_bytes(esc_pool_words(esc_total))) / (uint32_t)pixel_bytes);
+}
+
 // Lane-major copy of the word stream (k_transcode): row r holds the r-th word each of the batch's 1024 chains consumes.
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
@@ -93,7 +117,7 @@ struct RenderArgs {
     uint2 *win;               // [nB] LDS depth-window rectangle per batch: {x0 | y0<<16, w | h<<16}, w == 0: none
     pcr_render_stats *stats;  // device: one partial record per prepass workgroup
     int variant_hqs;          // LOD expression variant
-    int win_capacity;         // pixels the LDS window of the following k_render<MODE> can hold
+    int win_pixel_bytes;      // what a window pixel of the following k_render<MODE> takes in LDS (WIN_PIXEL_BYTES*)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -214,6 +238,7 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
     // Screen rectangle of the batch's bounding box: where k_render keeps its LDS copy of the framebuffer. This is
     // only a cache placement hint (points that land outside it take the global path), so it needs no exactness.
     uint2 wr = make_uint2(0, 0);
+    const int win_capacity = window_capacity((uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023], a.win_pixel_bytes);
     {
         // corner `lane` of the box, then min / max over the group's eight lanes
         const int c = lane;
@@ -232,13 +257,13 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
             int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
             int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
             int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
-            if (ww > 0 && wh > 0 && (int64_t)ww * wh > a.win_capacity && (int64_t)ww * wh <= 16 * (int64_t)a.win_capacity) {
+            if (ww > 0 && wh > 0 && (int64_t)ww * wh > win_capacity && (int64_t)ww * wh <= 16 * (int64_t)win_capacity) {
                 // too large for LDS: keep the central part of the rectangle (same aspect); the rest goes the global way
-                const float sc = sqrtf((float)a.win_capacity / ((float)ww * (float)wh));
+                const float sc = sqrtf((float)win_capacity / ((float)ww * (float)wh));
                 const int nw = max(1, (int)floorf((float)ww * sc)), nh = max(1, (int)floorf((float)wh * sc));
                 x0 += (ww - nw) / 2; y0 += (wh - nh) / 2; ww = nw; wh = nh;
             }
-            if (ww > 0 && wh > 0 && ww * wh <= a.win_capacity && x0 < 65536 && y0 < 65536)
+            if (ww > 0 && wh > 0 && ww * wh <= win_capacity && x0 < 65536 && y0 < 65536)
                 wr = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)ww | ((uint32_t)wh << 16));
         }
     }
@@ -298,16 +323,6 @@ __device__ __forceinline__ void window_row_col(uint32_t i, uint32_t ww, float in
     if (r < 0) { --y; r += (int32_t)ww; }
     else if (r >= (int32_t)ww) { ++y; r -= (int32_t)ww; }
     x = (uint32_t)r;
-}
-
-// How many of a batch's escape words k_render keeps in LDS: all of them plus ESC_SLACK words that follow them in memory
-// (the reference's tail over-reads, SURVEY B.4), or as many as the pool holds. A batch with more than that is flagged
-// (BF_GENERIC_SLOW_PATH) and its chains check every escape index: the first ESC_POOL_WORDS still come from LDS, only
-// the rest from global memory. (Pooling none of an oversized batch's escapes made that batch twice as slow, and a few
-// such batches made the whole launch 14 % longer: they finish last on their CUs.)
-__device__ __forceinline__ uint32_t esc_pool_words(uint32_t esc_total)
-{
-    return min(esc_total + (uint32_t)ESC_SLACK, (uint32_t)ESC_POOL_WORDS);
 }
 
 // One packed dword per table key (layout above): value and length of render.cu:435-439 in a single LDS read.
@@ -454,8 +469,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t tid = threadIdx.x;
 
     __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
-    __shared__ __align__(16) int32_t s_esc[ESC_POOL_WORDS];
-    __shared__ __align__(16) unsigned long long s_win[WIN_PIXELS];
+    __shared__ __align__(16) unsigned char s_dyn[DYN_LDS_BYTES];            // escape pool, then the framebuffer window
+    int32_t *const s_esc = reinterpret_cast<int32_t *>(s_dyn);
 
     // decoder table -> LDS (render.cu:383-395), four entries per thread, already packed by k_transcode
     const int32_t *tvalues = a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE;   // only for `wide` entries
@@ -477,13 +492,26 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // tail over-reads find in LDS what they would find in global memory; reads beyond even that, and
     // batches that do not fit, go to global memory (slow variant of the decode step).
     const uint32_t esc_lds = esc_pool_words(esc_total);
-    {   // all loads of a thread in flight together (ESC_POOL_WORDS / 1024 = 6 per thread)
-        int32_t v[ESC_POOL_WORDS / PCR_WORKGROUP_SIZE];
+    unsigned long long *const s_win = reinterpret_cast<unsigned long long *>(s_dyn + esc_pool_bytes(esc_lds));
+    const uint32_t win_cap = (uint32_t)window_capacity(esc_total, MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES);
+    {   // all loads of a thread in flight together, requested before the batch's escape count is known (7 per thread)
+        int32_t v[ESC_POOL_EAGER / PCR_WORKGROUP_SIZE];
 #pragma unroll
-        for (int k = 0; k < ESC_POOL_WORDS / PCR_WORKGROUP_SIZE; ++k) v[k] = sep_load(tid + k * PCR_WORKGROUP_SIZE);
+        for (int k = 0; k < ESC_POOL_EAGER / PCR_WORKGROUP_SIZE; ++k) v[k] = sep_load(tid + k * PCR_WORKGROUP_SIZE);
 #pragma unroll
-        for (int k = 0; k < ESC_POOL_WORDS / PCR_WORKGROUP_SIZE; ++k)
+        for (int k = 0; k < ESC_POOL_EAGER / PCR_WORKGROUP_SIZE; ++k)
             if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = (int32_t)((uint32_t)v[k] + TE_BIAS);   // stored biased, like table values
+    }
+    if (esc_lds > (uint32_t)ESC_POOL_EAGER) {               // (uniform) an escape-heavy batch: the rest of its pool
+        int32_t v[(ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE];
+#pragma unroll
+        for (int k = 0; k < (ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE; ++k)
+            v[k] = sep_load(ESC_POOL_EAGER + tid + k * PCR_WORKGROUP_SIZE);
+#pragma unroll
+        for (int k = 0; k < (ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE; ++k) {
+            const uint32_t i = ESC_POOL_EAGER + tid + k * PCR_WORKGROUP_SIZE;
+            if (i < esc_lds) s_esc[i] = (int32_t)((uint32_t)v[k] + TE_BIAS);
+        }
     }
     uint32_t sp = tid ? (uint32_t)ssz[tid - 1] : 0u;        // :411-413 (batch-relative)
 
@@ -493,20 +521,21 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t wpix = ww * wh;                          // 0: no window for this batch
     const uint32_t W = (uint32_t)a.p.width;
     const float inv_ww = 1.0f / (float)max(ww, 1u);
-    // colour pass layout of the same 32 KiB: sums in the framebuffer's own packed format + the depth to test against
-    unsigned long long *const s_rg = s_win, *const s_ba = s_win + WIN_PIXELS_HQS;
-    uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * WIN_PIXELS_HQS);
+    // colour pass layout of the same bytes: sums in the framebuffer's own packed format + the depth to test against
+    unsigned long long *const s_rg = s_win, *const s_ba = s_win + win_cap;
+    uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * win_cap);
     {   // snapshot of the rectangle, all loads of a thread in flight together (a stale value is a valid start)
-        unsigned long long v[(WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE];
+        constexpr int K_WIN = (WIN_PIXELS_MAX + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE;
+        unsigned long long v[K_WIN];
 #pragma unroll
-        for (int k = 0; k < (WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE; ++k) {
+        for (int k = 0; k < K_WIN; ++k) {
             const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
             uint32_t y, x;
             window_row_col(i, ww, inv_ww, y, x);
             v[k] = i < wpix ? a.f.fb[(size_t)(wy0 + y) * W + wx0 + x] : 0ull;
         }
 #pragma unroll
-        for (int k = 0; k < (WIN_PIXELS + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE; ++k) {
+        for (int k = 0; k < K_WIN; ++k) {
             const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
             if (i < wpix) {
                 if (MODE == MODE_HQS_COLOR) { s_depth[i] = (uint32_t)(v[k] >> 32); s_rg[i] = 0; s_ba[i] = 0; }

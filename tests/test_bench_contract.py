@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORD = os.path.join(ROOT, "profiles", "r01_v29_bench_basic.json")
+RECORD = os.path.join(ROOT, "profiles", "r01_v30_bench_basic.json")
 
 
 @pytest.fixture(scope="module")
