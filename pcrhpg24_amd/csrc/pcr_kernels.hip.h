@@ -276,15 +276,17 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
 // Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
 //   s_table  16 KiB  decoder table packed to one dword per key: slow<<31 | (value + 2^20)<<10 | wide<<9 | escape<<8 | len
 //                    (an in-table value outside +-2^20 is flagged `wide` and re-read from global memory)
-//   s_esc    28 KiB  the escape ("separate") words of the batch, bulk-loaded coalesced up front (batches with
-//                    more than ESC_POOL_WORDS escapes read the ones past the pool from global memory)
-//   s_win    32 KiB  the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
+//   s_dyn    60 KiB  shared per batch (see DYN_LDS_BYTES above) between
+//   s_esc            the escape ("separate") words of the batch, bulk-loaded coalesced up front (batches with
+//                    more than ESC_POOL_WORDS escapes read the ones past the pool from global memory), and
+//   s_win            the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
 //                    and the atomicMin of every point that lands inside run on LDS (ds_read_b64 / ds_min_u64);
 //                    at the end the rectangle is merged into the global framebuffer with one row-coalesced
 //                    atomicMin per improved pixel. min is associative, so the result is the same u64 per pixel;
 //                    what changes is the number of global atomics: one per touched pixel and batch instead of
 //                    one per new per-pixel minimum.
-//   registers        three words of the chain's own sequence + two requested a point ahead (see the word window below)
+//   registers        the point's 64-bit window + the next two (LAYOUT_POINT_WINDOWS), or three words of the chain's own
+//                    sequence + two requested a point ahead (LAYOUT_WORDS; see the word window below)
 // Global loads left in the loop are consumed at least one iteration after they are issued.
 // ------------------------------------------------------------------------------------------------
 // BC1 block -> its four palette colours as 0x00BBGGRR (render.cu:31-62, always 4-colour mode)
