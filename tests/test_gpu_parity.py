@@ -182,6 +182,14 @@ def test_error_behaviour(renderer, stream200k):
     ctx.upload_batch(0, f.blob(0))
     with pytest.raises(P.PcrError, match="image size"):
         ctx.render_basic(q)
+    with pytest.raises(P.PcrError, match="image size"):
+        ctx.frame_begin(q)
+    with pytest.raises(P.PcrError, match="unknown stream layout"):
+        ctx.set_stream_layout(7)
+    with pytest.raises(P.PcrError, match="unknown render variant"):
+        ctx.set_render_variant(-1)
+    with pytest.raises(P.PcrError):
+        ctx.kernel_timing(-3)
     ctx.stream_unload()
 
 
