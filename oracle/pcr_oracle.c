@@ -316,7 +316,7 @@ void pcr_oracle_decode_batch(const pcr_oracle_stream *s, int64_t batch, int npr,
 /* ------------------------------------------------------------------------------------------------
  * rasterize variants
  * ---------------------------------------------------------------------------------------------- */
-enum { MODE_BASIC, MODE_HQS_DEPTH, MODE_HQS_COLOR };
+enum { MODE_BASIC, MODE_HQS_DEPTH, MODE_HQS_COLOR, MODE_TIE_COUNT };
 
 typedef struct {
     const pcr_oracle_stream *s;
@@ -328,6 +328,7 @@ typedef struct {
     float scalef[3], offf[3];    /* float path:  render.cu:469-470 */
     uint64_t *fb;                /* basic / hqs depth: written; hqs colour: read */
     uint64_t *rg, *ba;
+    uint32_t *tie;               /* MODE_TIE_COUNT: per pixel, bits 30:0 = points at the winning depth, bit 31 = one of them has another colour */
     size_t fb_elems;
 } raster_ctx;
 
@@ -360,6 +361,20 @@ static void sink_raster(void *vctx, int chain, int i, int32_t cx, int32_t cy, in
     int64_t pix = (int64_t)(int)ix + (int64_t)(int)iy * p->width;   /* :284-285 */
     if (pix < 0 || (size_t)pix >= c->fb_elems) return;
     uint32_t depth = f32_bits(pos.w);                                /* :287 */
+
+    if (c->mode == MODE_TIE_COUNT) {
+        /* Second walk over a finished basic frame: which pixels had several points at the winning depth? Where those
+         * points differ in colour the reference's result depends on the order its threads ran in (its pre-read compares
+         * depth<<32|pointIndex, render.cu:294-299); "plain min" picks the smallest colour. */
+        uint64_t win = c->fb[pix];
+        if ((uint32_t)(win >> 32) == depth) {
+            uint32_t t = c->tie[pix];
+            if ((t & 0x7FFFFFFFu) != 0x7FFFFFFFu) ++t;
+            if (pcr_oracle_decode_bc1(index, c->s->colors) != (uint32_t)win) t |= 0x80000000u;
+            c->tie[pix] = t;
+        }
+        return;
+    }
 
     if (c->mode == MODE_HQS_COLOR) {
         uint64_t old = c->fb[pix];
@@ -403,7 +418,7 @@ static void render_range(const pcr_oracle_stream *s, const pcr_render_params *p,
         const pcr_gpu_batch *b = &s->batches[bi];
         int npr = 0, use_double = 0;
         if (stats) stats->batches_total++;
-        int variant = mode == MODE_BASIC ? PCR_ORACLE_MEM_ITER : PCR_ORACLE_HQS;
+        int variant = (mode == MODE_BASIC || mode == MODE_TIE_COUNT) ? PCR_ORACLE_MEM_ITER : PCR_ORACLE_HQS;
         if (!pcr_oracle_batch_lod(b, p, variant, &npr, &use_double)) {
             if (stats) stats->batches_culled++;
             continue;
@@ -439,6 +454,42 @@ void pcr_oracle_render_hqs_color(const pcr_oracle_stream *s, const pcr_render_pa
                                  uint64_t *rg, uint64_t *ba, pcr_render_stats *stats)
 {
     render_range(s, p, MODE_HQS_COLOR, first, count, (uint64_t *)fb, rg, ba, stats);
+}
+
+/* Depth ties of a finished basic frame `fb` (rendered from the same batches with the same parameters): pixels whose
+ * winning depth was reached by more than one point, and those among them where the tied points differ in colour. */
+int pcr_oracle_count_depth_ties(const pcr_oracle_stream *s, const pcr_render_params *p, int64_t first, int64_t count,
+                                const uint64_t *fb, int64_t *tie_pixels, int64_t *tie_pixels_other_colour)
+{
+    size_t n = pcr_fb_elems(p->width, p->height);
+    uint32_t *tie = (uint32_t *)calloc(n, sizeof *tie);
+    if (!tie) return -1;
+    raster_ctx c;
+    memset(&c, 0, sizeof c);
+    /* render_range sets the per-batch fields; the tie plane travels in a context of the same shape */
+    {
+        c.s = s; c.p = p; c.mode = MODE_TIE_COUNT; c.fb = (uint64_t *)fb; c.tie = tie; c.fb_elems = n;
+        for (int64_t bi = first; bi < first + count; ++bi) {
+            const pcr_gpu_batch *b = &s->batches[bi];
+            int npr = 0, use_double = 0;
+            if (!pcr_oracle_batch_lod(b, p, PCR_ORACLE_MEM_ITER, &npr, &use_double)) continue;
+            c.batch = bi; c.npr = npr; c.use_double = use_double;
+            c.scale[0] = b->scale_x; c.scale[1] = b->scale_y; c.scale[2] = b->scale_z;
+            c.offd[0] = b->offset_x - b->las_min_x;
+            c.offd[1] = b->offset_y - b->las_min_y;
+            c.offd[2] = b->offset_z - b->las_min_z;
+            for (int k = 0; k < 3; ++k) { c.scalef[k] = (float)c.scale[k]; c.offf[k] = (float)c.offd[k]; }
+            for (int cl = 0; cl < 32; ++cl) decode_cluster(s, bi, cl, npr, sink_raster, &c);
+        }
+    }
+    int64_t any = 0, other = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if ((tie[i] & 0x7FFFFFFFu) >= 2) ++any;
+        if (tie[i] & 0x80000000u) ++other;
+    }
+    free(tie);
+    *tie_pixels = any; *tie_pixels_other_colour = other;
+    return 0;
 }
 
 /* Multi-threaded basic render for the CPU baseline: batches striped over threads,

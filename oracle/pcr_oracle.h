@@ -62,6 +62,12 @@ void pcr_oracle_render_basic(const pcr_oracle_stream *s, const pcr_render_params
 int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_params *p,
                                int64_t first, int64_t count, uint64_t *fb, int nthreads,
                                pcr_render_stats *stats);
+/* Depth ties of a finished basic frame (fb = pcr_oracle_render_basic of the same batches and parameters): *tie_pixels =
+ * pixels whose winning depth was reached by more than one point; *tie_pixels_other_colour = those where a tied point has
+ * another colour than the winner — there the reference's result depends on thread order (render.cu:294-299 pre-reads
+ * depth<<32|pointIndex) while this build and the oracle define "plain min of depth<<32|colour" (SURVEY Appendix C.5). */
+int pcr_oracle_count_depth_ties(const pcr_oracle_stream *s, const pcr_render_params *p, int64_t first, int64_t count,
+                                const uint64_t *fb, int64_t *tie_pixels, int64_t *tie_pixels_other_colour);
 /* huffman_hqs/depth.cu */
 void pcr_oracle_render_hqs_depth(const pcr_oracle_stream *s, const pcr_render_params *p,
                                  int64_t first, int64_t count, uint64_t *fb, pcr_render_stats *stats);

@@ -49,6 +49,8 @@ def lib() -> C.CDLL:
         L.pcr_oracle_render_basic_mt.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.POINTER(RenderStats)]
         L.pcr_oracle_render_hqs_color.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
         L.pcr_oracle_render_hqs_color.restype = None
+        L.pcr_oracle_count_depth_ties.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int64, C.c_int64, C.c_void_p,
+                                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.pcr_oracle_resolve_basic.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p]
         L.pcr_oracle_resolve_basic.restype = None
         L.pcr_oracle_resolve_hqs.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -141,6 +143,15 @@ class OracleFile:
         else:
             lib().pcr_oracle_render_basic(self.stream, C.byref(p), first, count, fb.ctypes.data, C.byref(st))
         return fb, st.as_dict()
+
+    def count_depth_ties(self, p: RenderParams, fb: np.ndarray, first=0, count=None) -> tuple[int, int]:
+        """(pixels of the finished basic frame `fb` whose winning depth several points reached, those among them where
+        the tied points differ in colour: the pixels at which the reference's own result is schedule dependent)."""
+        count = self.num_batches - first if count is None else count
+        a, b = C.c_int64(), C.c_int64()
+        rc = lib().pcr_oracle_count_depth_ties(self.stream, C.byref(p), first, count, fb.ctypes.data, C.byref(a), C.byref(b))
+        assert rc == 0
+        return a.value, b.value
 
     def render_hqs_depth(self, p: RenderParams, fb=None, first=0, count=None):
         fb = self.new_fb(p) if fb is None else fb

@@ -12,6 +12,18 @@ source text is stored.
   huffman_ref_vectors.npz    seeded symbol chains, the REFERENCE Huffman<int32_t> dictionary/table
                              (include/huffman.h:94-113,180-240) and its packed words / escapes / per-word
                              completion indices (huffman.h:242-300) for them
+  ref_packed_batch.huffman   two full batches (131 072 points) whose every code bit came out of the REFERENCE's own
+                             library: Morton order from src/mymorton.h, dictionary + 4096-entry table from
+                             Huffman<int32_t>::{calculate_frequencies, generate_huffman_tree_priority_queue,
+                             create_dictionary_pjn, get_gpu_huffman_table_pjn} fed as Batch::calculate feeds them
+                             (src/preprocess.cpp:757-770), every chain's words / escapes / completion indices from
+                             compress_udtype_subarray_fast_pjn_idea (include/huffman.h:242-300), colour blocks from
+                             rgbcx::encode_bc1(level 8) as src/preprocess.cpp:282-297 calls it. Only the (time, lane)
+                             interleave of src/preprocess.cpp:552-573 and the record layout of
+                             include/BatchDumpData.h:151-202 are restated here (those sources need GL/CUDA headers).
+  ref_packed_batch_expected.json   cameras, SHA-256 of the oracle's framebuffers / sums / resolves for that file, the
+                             in-chain positions at which the lockstep decode differs from the reference's own scalar
+                             decoder (huffman.h:433-477; must all be SURVEY B.4 tail positions) and the depth-tie counts
 """
 import ctypes as C
 import hashlib
@@ -118,10 +130,170 @@ def huffman_ref():
     print("huffman:", {k: len(d["dict_symbols"]) for k, d in cases.items()})
 
 
+def assemble_huffman_file(records) -> bytes:
+    """5 x int64 header, batch size table, batch records (include/BatchDumpData.h:151-202 field
+    order; src/preprocess.cpp:1205-1234 for the header)."""
+    import struct
+    blobs, enc_b, sep_b, clu_b, npts = [], 0, 0, 0, 0
+    for r in records:
+        fixed = struct.pack("<5i", r["point_offset"], 65536, 1024, 64, 1)
+        fixed += struct.pack("<6d", *r["las_scale"], *r["las_offset"])
+        fixed += struct.pack("<12f", *r["bbox_min"], *r["bbox_max"], *r["las_min"], *r["las_max"])
+        fixed += struct.pack("<2i", 4096, 32)
+        assert len(fixed) == 124
+        body = b"".join(np.ascontiguousarray(r[k], dt).tobytes() for k, dt in (
+            ("start_values", np.int32), ("separate_sizes", np.int32), ("decoder_values", np.int32), ("decoder_cw_len", np.int32),
+            ("cluster_sizes", np.int32), ("encoding", np.uint32), ("separate", np.int32), ("color", np.uint8)))
+        blobs.append(fixed + body)
+        enc_b += 4 * len(r["encoding"]); sep_b += 4 * len(r["separate"]); clu_b += 128; npts += 65536
+    head = struct.pack("<5q", npts, len(blobs), enc_b, sep_b, clu_b) + np.array([len(b) for b in blobs], np.int64).tobytes()
+    return head + b"".join(blobs)
+
+
+def ref_packed_batch():
+    """Two batches packed by the reference's own huffman.h / mymorton.h / rgbcx (oracle/_ref), see the module docstring."""
+    ref = refpin.ref_lib()
+    rng = np.random.default_rng(20241004)
+    # a 36 m x 36 m patch of a heightfield at the benchmark stream's density (0.1 m spacing, LAS scale 0.001): 362^2 points
+    side = 362
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="xy")
+    px = (100_000 + gx * 100 + rng.integers(-40, 41, gx.shape)).ravel().astype(np.int32)
+    py = (200_000 + gy * 100 + rng.integers(-40, 41, gy.shape)).ravel().astype(np.int32)
+    pz = (40_000 + 3000 * np.sin(px / 3000.0) * np.cos(py / 4100.0) + 400 * np.sin(px / 170.0 + py / 230.0)).astype(np.int64)
+    pz = (pz + rng.integers(-15, 16, pz.shape)).astype(np.int32)
+    cr = np.clip(128 + 100 * np.sin(px / 5000.0) + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
+    cg = np.clip(128 + 100 * np.cos(py / 7000.0) + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
+    cb = np.clip(90 + (pz - 36_000) // 60 + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
+    col = (cr | (cg << 8) | (cb << 16)).astype(np.uint32)
+    scale, offset = (0.001, 0.001, 0.001), (0.0, 0.0, 0.0)
+    las_min = tuple(float(a.min()) * 0.001 for a in (px, py, pz))
+    las_max = tuple(float(a.max()) * 0.001 for a in (px, py, pz))
+    n_in = len(px)
+    src_points = (px.copy(), py.copy(), pz.copy(), col.copy())
+    # src/preprocess.cpp:945-955: pad to a multiple of 65 536 by repeating the last point
+    pad = (-n_in) % 65536
+    px, py, pz, col = (np.concatenate([a, np.full(pad, a[-1], a.dtype)]) for a in (px, py, pz, col))
+    # src/preprocess.cpp:959-977 with the reference's own src/mymorton.h:39-58
+    order = np.zeros(len(px), np.uint32)
+    ref.ref_morton_order(px.ctypes.data, py.ctypes.data, pz.ctypes.data, len(px), order.ctypes.data)
+    px, py, pz, col = px[order], py[order], pz[order], col[order]
+
+    records, scalar_mismatch = [], []
+    for b in range(len(px) // 65536):
+        sl = slice(b * 65536, (b + 1) * 65536)
+        X, Y, Z, Cc = (a[sl].reshape(1024, 64) for a in (px, py, pz, col))
+        # Chain::calculate_deltas + interleave (src/preprocess.cpp:318-343); int32 wrap-around as the C++ does
+        d = np.zeros((1024, 64, 3), np.int32)
+        for k, A in enumerate((X, Y, Z)):
+            d[:, 1:, k] = (A[:, 1:].astype(np.int64) - A[:, :-1].astype(np.int64)).astype(np.int32)
+        chains = d.reshape(1024, 192)
+        rc = refpin.RefCode(chains.reshape(-1))                      # Batch::calculate: all_deltas in chain order (:757-770)
+        tv, tl = rc.table()
+        packed = [rc.pack(chains[c]) for c in range(1024)]           # Chain::encode (:345-365)
+        # the reference's own scalar decoder on each chain's own words must give the chain back (its ASSERT_DECOMPRESSION path)
+        for c in (0, 1, 511, 1023):
+            w, sp, _ = packed[c]
+            assert np.array_equal(rc.unpack(w, sp, 192), chains[c])
+        # Batch::encode_decode_bernhard (:540-587), restated: (time, lane) keys, stable sort, concatenate
+        enc, cluster_sizes = [], []
+        for wid in range(32):
+            pairs = []
+            for lane in range(32):
+                pairs.append(((-1, lane), 0)); pairs.append(((0, lane), 1))
+            for lane in range(32):
+                step = packed[wid * 32 + lane][2]
+                for i in range(2, len(step)):
+                    pairs.append(((int(step[i - 2]), lane), i))
+            pairs.sort()
+            for (_, lane), i in pairs:
+                enc.append(packed[wid * 32 + lane][0][i])
+            cluster_sizes.append(len(enc))
+        sep = np.concatenate([packed[c][1] for c in range(1024)]) if any(len(packed[c][1]) for c in range(1024)) else np.zeros(0, np.int32)
+        sep_sizes = np.cumsum([len(packed[c][1]) for c in range(1024)]).astype(np.int32)
+        # Chain::encode_color_bc1 (:282-297): the reference's rgbcx, 16 points per block, chain-major
+        blocks = np.zeros((4096, 8), np.uint8)
+        flat = np.ascontiguousarray(Cc.reshape(4096, 16))
+        for k in range(4096):
+            ref.ref_bc1_encode(flat[k].ctypes.data, blocks[k].ctypes.data)
+        mins = [int(A.min()) for A in (X, Y, Z)]; maxs = [int(A.max()) for A in (X, Y, Z)]
+        f32 = np.float32
+        records.append(dict(
+            point_offset=b * 65536, las_scale=scale, las_offset=offset,
+            # float(int) * double scale + double offset, stored in a float field (src/preprocess.cpp:1082-1087)
+            bbox_min=[float(f32(float(f32(m)) * s_ + o_)) for m, s_, o_ in zip(mins, scale, offset)],
+            bbox_max=[float(f32(float(f32(m)) * s_ + o_)) for m, s_, o_ in zip(maxs, scale, offset)],
+            las_min=[float(f32(v)) for v in las_min], las_max=[float(f32(v)) for v in las_max],
+            start_values=np.stack([X[:, 0], Y[:, 0], Z[:, 0]], 1).reshape(-1), separate_sizes=sep_sizes,
+            decoder_values=tv, decoder_cw_len=tl, cluster_sizes=np.array(cluster_sizes, np.int32),
+            encoding=np.array(enc, np.uint32), separate=sep.astype(np.int32), color=blocks.reshape(-1)))
+        records[-1]["_chains"] = chains
+        records[-1]["_xyz"] = np.stack([X, Y, Z], 2)
+    data = assemble_huffman_file(records)
+    open(os.path.join(G, "ref_packed_batch.huffman"), "wb").write(data)
+
+    # what the lockstep (kernel-order) decode makes of it, against the source points and the reference's scalar decoder
+    of = oracle.OracleFile(data)
+    tail_positions, wrong_points = [], 0
+    for b, r in enumerate(records):
+        dec = of.decode_batch(b)                                    # (1024, 64, 3) absolute coordinates
+        bad = np.argwhere((dec != r["_xyz"]).any(axis=2))
+        wrong_points += len(bad)
+        tail_positions += [int(i) for _, i in bad]
+    # this repository's own encoder on the same points: everything but the colour blocks (and the symbols parked in escape
+    # table slots, which no decoder reads) should be what the reference's library produced
+    las = P.LasInfo()
+    for k in range(3):
+        las.scale[k] = scale[k]; las.offset[k] = offset[k]; las.min[k] = las_min[k]; las.max[k] = las_max[k]
+    own, _ = P.encode_points(*src_points, las, morton_sort=True, nthreads=1)
+    own_of = oracle.OracleFile(bytes(own.view()))
+    same = {"encoded_words": bool(np.array_equal(own_of.encoded()[:int(of.s.encoded_words)], of.encoded())),
+            "escape_words": bool(np.array_equal(own_of.separate()[:int(of.s.separate_words)], of.separate())),
+            "colour_blocks_equal": int(sum(bytes(own.view())[-32768 * (len(records) - b):][:32768] == r["color"].tobytes() for b, r in enumerate(records)))}
+    W = H = 512
+    cams = {
+        # kernel-space positions are relative to the LAS minimum (render.cu:399-400): the patch spans [0, 36] m
+        "patch": P.camera_orbit(-0.4, -0.6, 60.0, (18.0, 18.0, 3.0), W, H),
+        "near": P.camera_orbit(0.9, -0.35, 14.0, (12.0, 26.0, 3.0), W, H),
+        "far": P.camera_orbit(2.2, -0.8, 420.0, (18.0, 18.0, 3.0), W, H),          # small on screen: the LOD percentage decides
+    }
+    out = {"stream_sha256": hashlib.sha256(data).hexdigest(), "width": W, "height": H,
+           "source_points": n_in, "padded_points": len(px), "batches": len(records),
+           "encoded_bits_per_point": round(32.0 * sum(len(r["encoding"]) for r in records) / len(px), 3),
+           "escape_words": int(sum(len(r["separate"]) for r in records)),
+           "own_encoder_on_same_points": same,
+           "lockstep_vs_source": {"wrong_points": wrong_points, "min_in_chain_position": min(tail_positions) if tail_positions else None,
+                                  "positions_histogram": {str(k): int(v) for k, v in zip(*np.unique(tail_positions, return_counts=True))}},
+           "cases": []}
+    for name, p in cams.items():
+        for lod, cull in ((100, 0), (10, 1)):
+            p.lod_percent = lod; p.enable_frustum_culling = cull
+            fb, s1 = of.render_basic(p)
+            ties = of.count_depth_ties(p, fb)
+            rgba = oracle.resolve_basic(p, fb)
+            hfb, s2 = of.render_hqs_depth(p)
+            rg, ba, _ = of.render_hqs_color(p, hfb)
+            hrgba = oracle.resolve_hqs(p, hfb, rg, ba)
+            out["cases"].append({
+                "camera": name, "lod_percent": lod,
+                "params": {"transform": list(p.transform), "world_view": list(p.world_view), "proj": list(p.proj),
+                           "enable_frustum_culling": p.enable_frustum_culling},
+                "stats_basic": s1, "stats_hqs": s2,
+                "covered_pixels": int((fb[:W * H] != 0xFFFFFFFFFFFFFFFF).sum()),
+                "depth_tie_pixels": ties[0], "depth_tie_pixels_other_colour": ties[1],
+                "fb_basic_sha256": sha(fb), "rgba_basic_sha256": sha(rgba),
+                "fb_hqs_sha256": sha(hfb), "rg_sha256": sha(rg), "ba_sha256": sha(ba), "rgba_hqs_sha256": sha(hrgba),
+            })
+    json.dump(out, open(os.path.join(G, "ref_packed_batch_expected.json"), "w"), indent=1)
+    print("ref_packed_batch:", len(data), "bytes;", out["encoded_bits_per_point"], "bit/pt;", out["escape_words"], "escape words;",
+          "lockstep-vs-source wrong points", wrong_points, "min pos", out["lockstep_vs_source"]["min_in_chain_position"],
+          "; own encoder", same, "; covered", [c["covered_pixels"] for c in out["cases"]], "ties", [(c["depth_tie_pixels"], c["depth_tie_pixels_other_colour"]) for c in out["cases"]])
+
+
 if __name__ == "__main__":
     config1()
     if os.path.exists(oracle.REF_LIB):
         bc1_ref()
         huffman_ref()
+        ref_packed_batch()
     else:
         print("oracle/_ref/libpcr_ref.so missing: reference-derived fixtures not regenerated")
