@@ -44,6 +44,18 @@ struct pcr_ctx {
     uint32_t *d_lod = nullptr;
     uint2 *d_win = nullptr;
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
+    // dense lists of the batches a frame draws (k_lod_prepass): d_order[0..nB) ordinary, [nB..2nB) BF_GENERIC_SLOW_PATH;
+    // d_order_count = two {ordinary, generic} counter pairs used alternately, each prepass launch zeroes the other pair
+    uint32_t *d_order = nullptr;
+    uint32_t *d_order_count = nullptr;
+    int order_parity = 0;                       // the pair the NEXT prepass launch counts into
+    int frame_parity = 0;                       // the pair the last prepass launch counted into (what k_render reads)
+    // "some batch of this stream was ever flagged BF_GENERIC_SLOW_PATH": set on the device by k_transcode, copied to a
+    // pinned word behind every transcode; while the copy is in flight the answer is "maybe" and the checked kernel is launched
+    uint32_t *d_any_generic = nullptr;
+    uint32_t *h_any_generic = nullptr;
+    hipEvent_t any_generic_ev = nullptr;
+    bool any_generic_pending = false;
     uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
     uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
     uint2 *d_point_windows = nullptr;           // PCR_LAYOUT_POINT_WINDOWS: 64-bit view per point (k_transcode), PW_ROWS x 1024 per batch
@@ -146,6 +158,10 @@ void free_stream_buffers(pcr_ctx *c)
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); c->transcoded = 0;
+    dfree(c->d_order); dfree(c->d_order_count); dfree(c->d_any_generic); c->order_parity = c->frame_parity = 0;
+    if (c->any_generic_pending && c->any_generic_ev) (void)hipEventSynchronize(c->any_generic_ev);
+    c->any_generic_pending = false;
+    if (c->h_any_generic) *c->h_any_generic = 0;
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0; c->prepass_ready = false;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
@@ -205,7 +221,25 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.s = make_stream_view(c);
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
     a.lod = c->d_lod; a.win = c->d_win; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
+    a.order = c->d_order;
+    a.order_count = c->d_order_count + 2 * c->frame_parity;
+    a.order_count_next = c->d_order_count + 2 * (c->frame_parity ^ 1);
     return a;
+}
+
+// Arguments of a launch that runs the prepass: it counts into the free pair of list counters and zeroes the other one.
+RenderArgs make_prepass_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
+{
+    c->frame_parity = c->order_parity;
+    c->order_parity ^= 1;
+    return make_args(c, p, variant_hqs);
+}
+
+// Does the stream hold a batch for the checked kernel? false only when the device has said so.
+bool maybe_generic_batches(pcr_ctx *c)
+{
+    if (c->any_generic_pending && hipEventQuery(c->any_generic_ev) == hipSuccess) c->any_generic_pending = false;
+    return c->any_generic_pending || *c->h_any_generic != 0;
 }
 
 // Lane-major word sequences + packed tables (k_transcode) for every loaded batch that does not have them yet. A batch is
@@ -220,8 +254,12 @@ void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
     if (end > c->transcoded) {
         hipLaunchKernelGGL(k_transcode, dim3((unsigned)(end - c->transcoded)), dim3(PCR_WORKGROUP_SIZE), 0, st,
                            make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows,
-                           (int)c->transcoded);
+                           c->d_any_generic, (int)c->transcoded);
         c->transcoded = std::max(c->transcoded, final_end);
+        // the sticky "some batch needs the checked kernel" word follows every transcode to the host
+        (void)hipMemcpyAsync(c->h_any_generic, c->d_any_generic, 4, hipMemcpyDeviceToHost, st);
+        (void)hipEventRecord(c->any_generic_ev, st);
+        c->any_generic_pending = true;
     }
 }
 
@@ -233,12 +271,14 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const int64_t nB = c->visible_batches();         // "don't execute a workgroup until all points inside are loaded"
     c->last_frame_batches = nB;
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
-    RenderArgs a = make_args(c, p, MODE != MODE_BASIC);
-    a.win_pixel_bytes = MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
-    const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == a.variant_hqs &&
-                              c->prepass_win_pixel_bytes == a.win_pixel_bytes && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
+    const int win_pixel_bytes = MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
+    const int variant_hqs = MODE != MODE_BASIC;
+    const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
+                              c->prepass_win_pixel_bytes == win_pixel_bytes && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
     c->prepass_ready = false;
+    RenderArgs a = have_prepass ? make_args(c, p, variant_hqs) : make_prepass_args(c, p, variant_hqs);
+    a.win_pixel_bytes = win_pixel_bytes;
     if (!have_prepass) {
         c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
         hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
@@ -252,10 +292,16 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     // is bound by global framebuffer traffic and the 3 B per point of the packed words win (0.70 ms against 0.75 ms).
     const bool windows = c->layout == PCR_LAYOUT_POINT_WINDOWS && c->variant != PCR_VARIANT_WORDS &&
                          (c->variant == PCR_VARIANT_POINT_WINDOWS || (int64_t)c->width * c->height <= nB * (int64_t)WIN_PIXELS);
-    if (windows)
-        hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
-    else
-        hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    // The grid is sized for "every batch visible"; workgroups beyond the prepass's dense list return at once. The checked
+    // kernel (second list) is launched only if the stream may hold a flagged batch.
+    const bool generic = maybe_generic_batches(c);
+    if (windows) {
+        hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+    }
     if (timed) { HIP_TRY(c, hipEventRecord(c->kt_end[slot], c->stream)); ++c->kt_samples; }
     if (c->kt_every > 0) ++c->kt_launches;
     HIP_TRY(c, hipGetLastError());
@@ -289,10 +335,13 @@ int pcr_create(int device, pcr_ctx **out)
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&c->arena_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->arena_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->any_generic_ev, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_any_generic, 64, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&c->d_stats, PCR_STATS_PARTIALS * sizeof(pcr_render_stats)) != hipSuccess) {
         pcr_destroy(c);
         return set_err(nullptr, PCR_E_HIP, "could not create stream/events");
     }
+    *c->h_any_generic = 0;
     c->stream = c->own_stream;
     *out = c;
     return PCR_OK;
@@ -315,6 +364,8 @@ void pcr_destroy(pcr_ctx *c)
         if (c->kt_begin[i]) (void)hipEventDestroy(c->kt_begin[i]);
         if (c->kt_end[i]) (void)hipEventDestroy(c->kt_end[i]);
     }
+    if (c->any_generic_ev) (void)hipEventDestroy(c->any_generic_ev);
+    if (c->h_any_generic) (void)hipHostFree(c->h_any_generic);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (hipEvent_t e : c->loader_events) (void)hipEventDestroy(e);
@@ -366,6 +417,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB)) || (rc = dalloc_zero(c, c->d_win, nB)) ||
         (rc = dalloc_zero(c, c->d_lane_words, nB * LW_ROWS * PCR_WORKGROUP_SIZE)) || (rc = dalloc_zero(c, c->d_batch_flags, nB)) ||
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE)) ||
+        (rc = dalloc_zero(c, c->d_order, 2 * nB)) || (rc = dalloc_zero(c, c->d_order_count, 4)) || (rc = dalloc_zero(c, c->d_any_generic, 1)) ||
         (c->next_layout == PCR_LAYOUT_POINT_WINDOWS &&
          (rc = dalloc_zero(c, c->d_point_windows, (nB * PW_ROWS + PW_GUARD_ROWS) * PCR_WORKGROUP_SIZE)))) {
         free_stream_buffers(c);
@@ -533,6 +585,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
 int pcr_upload_tail(pcr_ctx *c, const uint32_t *enc, size_t n_enc, const int32_t *sep, size_t n_sep)
 {
     if (!c) return PCR_E_ARG;
+    c->prepass_ready = false;        // what pcr_frame_begin prepared no longer matches the context's state
     if (!c->stream_open) return set_err(c, PCR_E_ARG, "no stream");
     if (n_enc > PCR_ENCODED_PAD_WORDS || n_sep > PCR_SEPARATE_PAD_WORDS)
         return set_err(c, PCR_E_ARG, "tail larger than the pads (%d / %d words)", PCR_ENCODED_PAD_WORDS, PCR_SEPARATE_PAD_WORDS);
@@ -622,6 +675,7 @@ int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
 int pcr_set_image_size(pcr_ctx *c, int w, int h)
 {
     if (!c) return PCR_E_ARG;
+    c->prepass_ready = false;        // what pcr_frame_begin prepared no longer matches the context's state
     if (w <= 0 || h <= 0 || (int64_t)w * (h + 1) + 1 > 0x7FFFFFFF) return set_err(c, PCR_E_ARG, "bad image size %dx%d", w, h);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -641,6 +695,7 @@ int pcr_set_image_size(pcr_ctx *c, int w, int h)
 int pcr_clear(pcr_ctx *c)
 {
     if (!c) return PCR_E_ARG;
+    c->prepass_ready = false;        // what pcr_frame_begin prepared no longer matches the context's state
     if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
     HIP_TRY(c, hipSetDevice(c->device));
     // huffman_hqs.h:267-269. HuffmanMemIter clears only fb (huffman_mem_iter_cuda.h:250-252); RG/BA are re-zeroed only
@@ -664,7 +719,8 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     if (nB == 0) return pcr_clear(c);
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
-    RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
+    if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // the prepass sorts batches by what k_transcode found out about them
+    RenderArgs a = make_prepass_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
@@ -771,6 +827,7 @@ int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
     if (rc) return rc;
     const int64_t nB = c->las_loaded;
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }     // compute_loop_las_cuda.h:107
+    c->prepass_ready = false;        // d_stats is shared with the Huffman methods' prepass
     LasArgs a;
     a.p = *p;
     a.s.batches = c->d_xyzb; a.s.xyz12 = c->d_xyz12; a.s.xyz8 = c->d_xyz8; a.s.xyz4 = c->d_xyz4; a.s.num_batches = nB;
@@ -882,6 +939,7 @@ void *pcr_device_ba(pcr_ctx *c) { return c ? c->ba : nullptr; }
 int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
 {
     if (!c) return PCR_E_ARG;
+    c->prepass_ready = false;        // what pcr_frame_begin prepared no longer matches the context's state
     if (!c->own_fb) return set_err(c, PCR_E_ARG, "call pcr_set_image_size first");
     // pointers are captured by value at enqueue time: switching them does not disturb work already enqueued
     uint64_t *nrg = rg ? (uint64_t *)rg : c->own_rg, *nba = ba ? (uint64_t *)ba : c->own_ba;

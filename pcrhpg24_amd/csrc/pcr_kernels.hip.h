@@ -75,9 +75,14 @@ enum { LAYOUT_WORDS = 0, LAYOUT_POINT_WINDOWS = 1 };
 // batch_flags: set when some chain of the batch can meet an in-table value outside the packed entry's range or read an
 // escape word outside k_render's LDS pool (k_transcode walks all 192 symbols of every chain, garbage tails included)
 constexpr uint32_t BF_GENERIC_SLOW_PATH = 1u;
-// packed table entry: byte 0 = len, bit 31 = escape or wide (value not in the entry), bits 30:10 = value + TE_BIAS
-constexpr uint32_t TE_LEN = 0xFFu, TE_SLOW = 0x80000000u, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u, TE_BIAS = 1u << 20;
+// packed table entry: byte 0 = len, bits 31:10 = the value as a signed 22-bit number -- (int32)entry >> 10 is the delta, no
+// bias to remove -- except that the most negative one, TE_SLOW_VALUE, is reserved: "the value is not in the entry" (an escape,
+// bit 8, or an in-table value outside (-2^21, 2^21), bit 9). Cost model behind the layout (tools/exp/instr_rate2.hip, gfx950):
+// v_ashrrev_i32 / v_add_u32 / v_sub_u32 / v_and_b32 on VGPRs and constants issue in ~2.3 cycles per wave64, anything VOP3,
+// SDWA, 64-bit, packed, compare, convert or with an SGPR operand in ~4.2.
+constexpr uint32_t TE_LEN = 0xFFu, TE_ESCAPE = 0x100u, TE_WIDE = 0x200u;
 constexpr int TE_VALUE_SHIFT = 10;
+constexpr int32_t TE_SLOW_VALUE = -(1 << 21);
 
 // Device-side view of the loaded stream (own layout; the reference keeps nine flat CuBuffers,
 // HuffmanLasLoader.h:39-47). Tables are stored as int32 values + int8 lengths (the reference narrows the
@@ -116,6 +121,14 @@ struct RenderArgs {
     uint32_t *lod;            // [nB]
     uint2 *win;               // [nB] LDS depth-window rectangle per batch: {x0 | y0<<16, w | h<<16}, w == 0: none
     pcr_render_stats *stats;  // device: one partial record per prepass workgroup
+    // Dense lists of the batches k_render has to draw, written by the prepass (frustum-culled batches and batches whose
+    // level of detail is zero points are left out): order[0 .. nB) the ordinary ones, order[nB .. 2 nB) those flagged
+    // BF_GENERIC_SLOW_PATH (drawn by the checked variant of the kernel). order_count[kind] = entries of list `kind` for
+    // this frame; order_count_next = the pair the NEXT prepass launch will count into, zeroed by this one (the two pairs
+    // alternate, so no launch is spent on zeroing and nothing is zeroed while it is read: launches of a stream run in order).
+    uint32_t *order;
+    uint32_t *order_count;
+    uint32_t *order_count_next;
     int variant_hqs;          // LOD expression variant
     int win_pixel_bytes;      // what a window pixel of the following k_render<MODE> takes in LDS (WIN_PIXEL_BYTES*)
 };
@@ -172,9 +185,39 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
 __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t block)
 {
     const int64_t b = ((int64_t)block * PREPASS_THREADS + threadIdx.x) / PREPASS_LANES;
+    const int lane = (int)(threadIdx.x % PREPASS_LANES);
     pcr_render_stats st = {0, 0, 0, 0};
-    if (b < a.s.num_batches) lod_prepass_batch(a, b, (int)(threadIdx.x % PREPASS_LANES), st);   // uniform per 8-lane group
-    commit_stats(st, a.stats);
+    // what k_render has to do for the group's batch: 0 nothing (culled, or no point to draw), 1 draw, 2 draw with the checked variant
+    __shared__ uint32_t s_kind[PREPASS_BATCHES];
+    if (lane == 0) s_kind[threadIdx.x / PREPASS_LANES] = 0;
+    if (block == 0 && threadIdx.x < 2) a.order_count_next[threadIdx.x] = 0;
+    if (b < a.s.num_batches) {
+        lod_prepass_batch(a, b, lane, st);                                                       // uniform per 8-lane group
+        if (lane == 0) {
+            const uint32_t lod = a.lod[b];
+            if (!(lod & LOD_CULLED) && (lod & LOD_NPR_MASK))
+                s_kind[threadIdx.x / PREPASS_LANES] = (a.s.batch_flags[b] & BF_GENERIC_SLOW_PATH) ? 2u : 1u;
+        }
+    }
+    commit_stats(st, a.stats);                              // (barriers inside: s_kind is complete afterwards)
+    // Compaction of the visible batches: one ballot and one prefix count per list in the workgroup's first wave, one
+    // global atomic per workgroup and list. Batches keep their file (Morton) order inside a workgroup's run of
+    // PREPASS_BATCHES; runs land in the order their workgroups get here.
+    if (threadIdx.x < 64) {
+        const uint32_t kind = threadIdx.x < PREPASS_BATCHES ? s_kind[threadIdx.x] : 0u;
+        const uint64_t below = (1ull << threadIdx.x) - 1ull;
+#pragma unroll
+        for (uint32_t k = 1; k <= 2; ++k) {
+            const uint64_t m = __ballot(kind == k);
+            if (m == 0) continue;                           // (wave-uniform)
+            uint32_t base = 0;
+            if (threadIdx.x == 0) base = atomicAdd(&a.order_count[k - 1], (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (kind == k)
+                a.order[(size_t)(k - 1) * (size_t)a.s.num_batches + base + (uint32_t)__popcll(m & below)] =
+                    block * PREPASS_BATCHES + threadIdx.x;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
@@ -289,22 +332,23 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
 //                    sequence + two requested a point ahead (LAYOUT_WORDS; see the word window below)
 // Global loads left in the loop are consumed at least one iteration after they are issued.
 // ------------------------------------------------------------------------------------------------
-// BC1 block -> its four palette colours as 0x00BBGGRR (render.cu:31-62, always 4-colour mode)
-struct Bc1Palette { uint32_t c0, c1, c2, c3, selectors; };
+// BC1 block -> its four palette colours (render.cu:31-62, always 4-colour mode), one register per channel: byte k of
+// r / g / b is that channel of palette entry k. A point's colour 0x00BBGGRR is then two v_perm_b32 with selectors built from
+// its 2-bit index -- five instructions per point, no compare/select chain.
+struct Bc1Palette { uint32_t r, g, b, selectors; };
 
 __device__ __forceinline__ Bc1Palette bc1_palette(uint2 blk)
 {
     const uint32_t l = blk.x & 0xFFFFu, h = blk.x >> 16;
-    const int cr0 = (l >> 11) & 31, cg0 = (l >> 5) & 63, cb0 = l & 31;
-    const int r0 = (cr0 << 3) | (cr0 >> 2), g0 = (cg0 << 2) | (cg0 >> 4), b0 = (cb0 << 3) | (cb0 >> 2);
-    const int cr1 = (h >> 11) & 31, cg1 = (h >> 5) & 63, cb1 = h & 31;
-    const int r1 = (cr1 << 3) | (cr1 >> 2), g1 = (cg1 << 2) | (cg1 >> 4), b1 = (cb1 << 3) | (cb1 >> 2);
-    auto rgb = [](int r, int g, int b) { return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16); };
+    const uint32_t cr0 = (l >> 11) & 31, cg0 = (l >> 5) & 63, cb0 = l & 31;
+    const uint32_t r0 = (cr0 << 3) | (cr0 >> 2), g0 = (cg0 << 2) | (cg0 >> 4), b0 = (cb0 << 3) | (cb0 >> 2);
+    const uint32_t cr1 = (h >> 11) & 31, cg1 = (h >> 5) & 63, cb1 = h & 31;
+    const uint32_t r1 = (cr1 << 3) | (cr1 >> 2), g1 = (cg1 << 2) | (cg1 >> 4), b1 = (cb1 << 3) | (cb1 >> 2);
+    auto four = [](uint32_t c0, uint32_t c1) {              // entries 2 and 3: (2 c0 + c1) / 3 and (c0 + 2 c1) / 3, integer division
+        return c0 | (c1 << 8) | (((c0 * 2 + c1) / 3) << 16) | (((c0 + c1 * 2) / 3) << 24);
+    };
     Bc1Palette p;
-    p.c0 = rgb(r0, g0, b0);
-    p.c1 = rgb(r1, g1, b1);
-    p.c2 = rgb((r0 * 2 + r1) / 3, (g0 * 2 + g1) / 3, (b0 * 2 + b1) / 3);
-    p.c3 = rgb((r0 + r1 * 2) / 3, (g0 + g1 * 2) / 3, (b0 + b1 * 2) / 3);
+    p.r = four(r0, r1); p.g = four(g0, g1); p.b = four(b0, b1);
     p.selectors = blk.y;                                    // byte 4 + local/4, bits 2*(local%4): render.cu:48
     return p;
 }
@@ -312,8 +356,9 @@ __device__ __forceinline__ Bc1Palette bc1_palette(uint2 blk)
 __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t local)
 {
     const uint32_t sel = (p.selectors >> (2 * local)) & 3u;
-    const uint32_t lo = (sel & 1u) ? p.c1 : p.c0, hi = (sel & 1u) ? p.c3 : p.c2;
-    return (sel & 2u) ? hi : lo;
+    // v_perm_b32(s0, s1, m): result byte i = byte m.byte[i] of {s0 (4..7), s1 (0..3)}, 0x0c = zero
+    const uint32_t rg = __builtin_amdgcn_perm(p.g, p.r, sel * 0x0101u + 0x0c0c0400u);          // g[sel] << 8 | r[sel]
+    return __builtin_amdgcn_perm(p.b, rg, (sel << 16) + 0x0c040100u);                          // b[sel] << 16 | rg
 }
 
 // Row/column of linear index i in a window of width ww (i < 2^23): one float multiply and a correction of at most one
@@ -328,13 +373,13 @@ __device__ __forceinline__ void window_row_col(uint32_t i, uint32_t ww, float in
 }
 
 // One packed dword per table key (layout above): value and length of render.cu:435-439 in a single LDS read.
+__device__ __forceinline__ bool table_value_fits(int32_t value) { return value > TE_SLOW_VALUE && value < -TE_SLOW_VALUE; }
 __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lbyte)
 {
     const int len = (int)(int8_t)lbyte;                             // render.cu:393 narrows to char
-    const uint32_t f = (uint32_t)abs(len) | (len <= 0 ? TE_ESCAPE | TE_SLOW : 0u);
-    if (len <= 0) return f;                                         // escapes never use the table value
-    const uint32_t biased = (uint32_t)value + TE_BIAS;              // fits 21 bits <=> -2^20 <= value < 2^20
-    return biased < (2u * TE_BIAS) ? ((biased << TE_VALUE_SHIFT) | f) : (f | TE_WIDE | TE_SLOW);
+    const uint32_t slow = (uint32_t)TE_SLOW_VALUE << TE_VALUE_SHIFT;
+    if (len <= 0) return slow | TE_ESCAPE | (uint32_t)abs(len);     // escapes never use the table value
+    return table_value_fits(value) ? (((uint32_t)value << TE_VALUE_SHIFT) | (uint32_t)len) : (slow | TE_WIDE | (uint32_t)len);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +396,8 @@ __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lby
 // without checking (batch_flags).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
-                                                                  uint32_t *packed_table, uint2 *point_windows, int first_batch)
+                                                                  uint32_t *packed_table, uint2 *point_windows,
+                                                                  uint32_t *any_generic, int first_batch)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -364,7 +410,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         // byte: |len| (render.cu:393, :439), bit 7: escape (len <= 0, as k_render packs it)
         auto entry = [&](uint32_t lbyte, int32_t value) -> uint32_t {
             const int len = (int)(int8_t)lbyte;
-            if (len > 0 && (uint32_t)value + TE_BIAS >= 2u * TE_BIAS) generic = true;      // "wide" entry of k_render's table
+            if (len > 0 && !table_value_fits(value)) generic = true;                       // "wide" entry of k_render's table
             return (uint32_t)abs(len) | (len <= 0 ? 0x80u : 0u);
         };
         reinterpret_cast<uint32_t *>(s_len)[tid] = entry(l4 & 0xFF, v.x) | (entry((l4 >> 8) & 0xFF, v.y) << 8) |
@@ -435,7 +481,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     const uint32_t sp0 = tid ? (uint32_t)ssz[tid - 1] : 0u;
     if (nesc && sp0 + nesc > esc_lds) generic = true;
     const int any = __syncthreads_or(generic ? 1 : 0);
-    if (tid == 0) batch_flags[b] = any ? BF_GENERIC_SLOW_PATH : 0u;
+    if (tid == 0) {
+        batch_flags[b] = any ? BF_GENERIC_SLOW_PATH : 0u;
+        if (any) atomicOr(any_generic, 1u);                 // sticky, per stream: the host launches the checked kernel only if set
+    }
 
     // Point windows: 64 bits of my word sequence from each point's first bit. A point's window can reach two words past
     // the last word the walk had fetched when the point began, so they are cut once the whole sequence is written
@@ -459,15 +508,18 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int MODE, int LAYOUT>
+// GENERIC: the checked variant of the decode step, for the batches the prepass put on the second list (flagged
+// BF_GENERIC_SLOW_PATH by k_transcode): escape indices are tested against the LDS pool, `wide` table values come from
+// global memory. A kernel of its own, so that the ordinary batches' loop carries neither its tests nor its code; the host
+// launches it only for streams that have such batches.
+template <int MODE, int LAYOUT, bool GENERIC>
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two workgroups per CU -> <= 64 VGPRs
 {
-    const uint32_t b = blockIdx.x;
+    if (blockIdx.x >= a.order_count[GENERIC ? 1 : 0]) return;              // the grid is sized for "every batch visible"
+    const uint32_t b = a.order[(GENERIC ? (size_t)a.s.num_batches : 0) + blockIdx.x];
     const uint32_t lod = a.lod[b];
-    if (lod & LOD_CULLED) return;
     const int npr = (int)(lod & LOD_NPR_MASK);
     const bool use_double = (lod & LOD_DOUBLE) != 0;
-    const bool generic_slow = (a.s.batch_flags[b] & BF_GENERIC_SLOW_PATH) != 0;
     const uint32_t tid = threadIdx.x;
 
     __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
@@ -502,7 +554,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         for (int k = 0; k < ESC_POOL_EAGER / PCR_WORKGROUP_SIZE; ++k) v[k] = sep_load(tid + k * PCR_WORKGROUP_SIZE);
 #pragma unroll
         for (int k = 0; k < ESC_POOL_EAGER / PCR_WORKGROUP_SIZE; ++k)
-            if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = (int32_t)((uint32_t)v[k] + TE_BIAS);   // stored biased, like table values
+            if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = v[k];
     }
     if (esc_lds > (uint32_t)ESC_POOL_EAGER) {               // (uniform) an escape-heavy batch: the rest of its pool
         int32_t v[(ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE];
@@ -512,10 +564,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #pragma unroll
         for (int k = 0; k < (ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE; ++k) {
             const uint32_t i = ESC_POOL_EAGER + tid + k * PCR_WORKGROUP_SIZE;
-            if (i < esc_lds) s_esc[i] = (int32_t)((uint32_t)v[k] + TE_BIAS);
+            if (i < esc_lds) s_esc[i] = v[k];
         }
     }
-    uint32_t sp = tid ? (uint32_t)ssz[tid - 1] : 0u;        // :411-413 (batch-relative)
+    uint32_t sp4 = tid ? 4u * (uint32_t)ssz[tid - 1] : 0u;  // :411-413 (batch-relative), as a byte offset into the pool
 
     // ---- framebuffer window of the batch's rectangle -> LDS --------------------------------------------------
     const uint2 wr = a.win[b];
@@ -593,7 +645,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // BC1 blocks of my chain (4 blocks of 16 points, 8 bytes each): the block of the current 16-point segment in
     // registers, the next one prefetched a whole segment (16 iterations) before its first use
     const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors) + ((size_t)b * 4096 + tid * 4);
-    Bc1Palette pal = {0, 0, 0, 0, 0};
+    Bc1Palette pal = {0, 0, 0, 0};
     uint2 cnext = make_uint2(0, 0);
     if (MODE != MODE_HQS_DEPTH) cnext = cblocks[0];
 
@@ -637,17 +689,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             }
             return;
         }
-        uint64_t key;
-        if (MODE == MODE_BASIC) {
-            // pre-read filter (:297-298) on the depth half only: result == min(depth<<32|colour) over all inside points
-            if (depth > (uint32_t)(old >> 32)) return;
-            key = ((uint64_t)depth << 32) | bc1_color(pal, (uint32_t)point & 15u);   // :299
-        } else {
-            key = ((uint64_t)depth << 32) | payload;                        // depth.cu:139-145
-        }
-        if (!(key < old)) return;
-        if (widx != NO_PIXEL) __hip_atomic_fetch_min(&s_win[widx], (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else                  atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);   // :300
+        // pre-read filter (:297-298) on the depth half only: the result is min(depth<<32|payload) over all inside points
+        // whatever passes it (min is idempotent), so ties go to the atomic instead of a 64-bit compare here. A point that
+        // is not inside carries depth 0xFFFFFFFF: above every real depth, and no pixel index if it slips through an
+        // empty pixel's all-ones word.
+        if (depth > (uint32_t)(old >> 32)) return;
+        const uint64_t key = ((uint64_t)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload);   // :299 / depth.cu:139-145
+        if (widx != NO_PIXEL)      __hip_atomic_fetch_min(&s_win[widx], (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if (pix != NO_PIXEL)  atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);   // :300
     };
 
     // End of a point: SFT0 - sft bits were consumed. Retire the 0..2 words that ran dry, pull in far0/far1 (requested a
@@ -659,7 +708,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             sft = SFT0;                                                                    \
             break;                                                                         \
         }                                                                                  \
-        const uint32_t u_ = spare + sft + (64u - SFT0);                                    \
+        const uint32_t u_ = spare + (sft & 63u) + (64u - SFT0);                            \
         const uint32_t k_ = u_ >> 5;               /* 2: no word retired, 1: one, 0: two */ \
         spare = u_ & 31u;                                                                  \
         const uint32_t n0_ = k_ == 2u ? w0 : k_ == 1u ? w1 : w2;                           \
@@ -675,7 +724,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         sft = SFT0;                                                                        \
     } while (0)
 
-    uint32_t pend_pix = NO_PIXEL, pend_widx = NO_PIXEL, pend_depth = 0;
+    constexpr uint32_t NO_DEPTH = 0xFFFFFFFFu;              // "not inside": a NaN for the colour pass's test, the largest key half otherwise
+    uint32_t pend_pix = NO_PIXEL, pend_widx = NO_PIXEL, pend_depth = NO_DEPTH;
     uint64_t pend_old = 0;
 
     const float *M = a.p.transform;
@@ -688,13 +738,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #else
     const int npr_run = npr;
 #endif
-    uint32_t toff_ahead = (uint32_t)(bits >> sft) & 0x3FFCu;
+    uint32_t toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
     uint32_t e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
     for (int seg = 0; seg < npr_run; seg += 16) {
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
-      if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, seg - 1);
-      pend_pix = NO_PIXEL;
+      scatter(pend_pix, pend_widx, pend_depth, pend_old, seg - 1);
+      pend_pix = pend_widx = NO_PIXEL; pend_depth = NO_DEPTH;
       if (MODE != MODE_HQS_DEPTH) {
           pal = bc1_palette(cnext);                     // once per 16 points instead of once per surviving point
           cnext = cblocks[min((seg >> 4) + 1, 3)];
@@ -722,33 +772,31 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 // `e` is the table entry of this symbol, fetched one step ahead; (bits >> sft) & 0x3FFC is 4 x the 12-bit
                 // window of :431-433 (== ((L|R) & mask) >> 20) at the current position, i.e. the byte offset of an entry
                 const uint32_t e = e_ahead, toff = toff_ahead;              // :435-436
-                sft -= e & TE_LEN;                                          // :439
-                toff_ahead = (uint32_t)(bits >> sft) & 0x3FFCu;
+                // :439. The whole entry is subtracted: byte 0 is the length, and only the low six bits of `sft` are ever
+                // used (the 64-bit shift below takes its count modulo 64; 14 <= true sft <= 50) -- a plain v_sub_u32
+                sft -= e;
+                toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
                 e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
-                uint32_t biased = e >> TE_VALUE_SHIFT;                      // value + TE_BIAS; the bias leaves with the delta add below
-                if ((int32_t)e < 0) {                                       // escape or wide
-                    if (!generic_slow) {                                    // (uniform) every such entry is an escape whose word is in the pool
-                        biased = (uint32_t)s_esc[sp];                       // the pool holds value + TE_BIAS; needed only by the delta add
-                        ++sp;
-                    } else {
-                        int32_t val;
-                        if (e & TE_ESCAPE) {                                // :438
-                            if (sp < esc_lds) {
-                                val = s_esc[sp] - (int32_t)TE_BIAS;
-                            } else {
-                                // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
-                                val = sep_load(sp);
-                                asm volatile("; escape word from global memory %0" : "+v"(val));
-                            }
-                            ++sp;
+                int32_t val = (int32_t)e >> TE_VALUE_SHIFT;                 // the delta itself (v_ashrrev_i32)
+                if (val == TE_SLOW_VALUE) {                                 // escape or wide
+                    if (!GENERIC) {                                         // every such entry is an escape whose word is in the pool
+                        val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
+                        sp4 += 4;
+                    } else if (e & TE_ESCAPE) {                             // :438
+                        if (sp4 < 4u * esc_lds) {
+                            val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
                         } else {
-                            val = tvalues[toff >> 2];
-                            asm volatile("; wide table value from global memory %0" : "+v"(val));
+                            // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
+                            val = sep_load(sp4 >> 2);
+                            asm volatile("; escape word from global memory %0" : "+v"(val));
                         }
-                        biased = (uint32_t)val + TE_BIAS;
+                        sp4 += 4;
+                    } else {
+                        val = tvalues[toff >> 2];
+                        asm volatile("; wide table value from global memory %0" : "+v"(val));
                     }
                 }
-                dec[j] = biased;
+                dec[j] = (uint32_t)val;
 #ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
                 {
                     uint32_t pad = tid;
@@ -758,9 +806,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
             }
         }
-        px = (int32_t)((uint32_t)px + dec[0] - TE_BIAS);                    // :454-456, :463
-        py = (int32_t)((uint32_t)py + dec[1] - TE_BIAS);
-        pz = (int32_t)((uint32_t)pz + dec[2] - TE_BIAS);
+        px = (int32_t)((uint32_t)px + dec[0]);                              // :454-456, :463
+        py = (int32_t)((uint32_t)py + dec[1]);
+        pz = (int32_t)((uint32_t)pz + dec[2]);
         PCR_ADVANCE_WORD_WINDOW();
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
@@ -768,7 +816,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
         // second half of rasterize() for point i-1: its framebuffer word has been in flight during this point's decode.
         // Done before point i is projected so that the projection can write the pending registers in place.
-        if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, i - 1);
+        scatter(pend_pix, pend_widx, pend_depth, pend_old, i - 1);
         float x, y, z;
         if (use_double) {                                                   // :459-461
             x = (float)__fma_rn((double)px, sx, ox);
@@ -784,7 +832,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const float qx = dot4(M + 0, x, y, z, 1.0f);
         const float qy = dot4(M + 4, x, y, z, 1.0f);
         const float qw = dot4(M + 12, x, y, z, 1.0f);
-        uint32_t pix = NO_PIXEL, widx = NO_PIXEL;
+        uint32_t pix = NO_PIXEL, widx = NO_PIXEL, depth = NO_DEPTH;
         // Inside test (:296) without dividing: for finite w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1]
         // exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w > 1 + 2^-24, which rounds above 1). The division
         // itself is the IEEE sequence hipcc emits for `/` with its range scaling removed, shared reciprocal, x and y
@@ -797,9 +845,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 const int ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);       // :283-284
                 const int iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
                 pix = (uint32_t)(ix + iy * a.p.width);                      // :285
-                if (pix >= a.f.fb_elems) pix = NO_PIXEL;
-                const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
-                if (rx < ww && ry < wh) widx = ry * ww + rx;
+                if (pix < a.f.fb_elems) {
+                    depth = __float_as_uint(qw);                            // :287
+                    const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
+                    if (rx < ww && ry < wh) widx = ry * ww + rx;
+                } else {
+                    pix = NO_PIXEL;
+                }
             }
         } else if (w_ok && fabsf(qx) <= qw && fabsf(qy) <= qw) {
             const float r0 = __builtin_amdgcn_rcpf(qw);
@@ -812,6 +864,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
             const int ix = (int)img.x, iy = (int)img.y;                             // :284
             pix = (uint32_t)(ix + iy * a.p.width);                                  // :285 (always < fb_elems here)
+            depth = __float_as_uint(qw);                                            // :287
             const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
             if (rx < ww && ry < wh) widx = ry * ww + rx;
         }
@@ -822,7 +875,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
         pend_pix = pix;
         pend_widx = widx;
-        pend_depth = __float_as_uint(qw);                                   // :287
+        pend_depth = depth;
         if (widx != NO_PIXEL)      pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[widx] << 32 : s_win[widx];   // :297 on the LDS copy
         else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
         if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
@@ -834,7 +887,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
       }
     }
-    if (pend_pix != NO_PIXEL) scatter(pend_pix, pend_widx, pend_depth, pend_old, npr_run - 1);
+    scatter(pend_pix, pend_widx, pend_depth, pend_old, npr_run - 1);
     if (MODE == MODE_HQS_COLOR) flush_run();
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
