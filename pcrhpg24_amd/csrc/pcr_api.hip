@@ -17,7 +17,7 @@
 
 using namespace pcr;
 
-constexpr int PCR_STATS_PARTIALS = 2048;        // ceil(65535 batches / 32 batches per prepass workgroup)
+constexpr int PCR_STATS_PARTIALS = PCR_MAX_PREPASS_WORKGROUPS;   // one partial record per prepass workgroup
 
 struct pcr_ctx {
     int device = 0;
@@ -44,12 +44,11 @@ struct pcr_ctx {
     uint32_t *d_lod = nullptr;
     uint2 *d_win = nullptr;
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
-    // dense lists of the batches a frame draws (k_lod_prepass): d_order[0..nB) ordinary, [nB..2nB) BF_GENERIC_SLOW_PATH;
-    // d_order_count = two {ordinary, generic} counter pairs used alternately, each prepass launch zeroes the other pair
+    // dense lists of the batches a frame draws, compacted by k_lod_prepass per workgroup (see RenderArgs): d_order[2][order_stride],
+    // d_chunk_count[2][PCR_MAX_PREPASS_WORKGROUPS]
     uint32_t *d_order = nullptr;
-    uint32_t *d_order_count = nullptr;
-    int order_parity = 0;                       // the pair the NEXT prepass launch counts into
-    int frame_parity = 0;                       // the pair the last prepass launch counted into (what k_render reads)
+    uint32_t *d_chunk_count = nullptr;
+    uint32_t order_stride = 0;
     // "some batch of this stream was ever flagged BF_GENERIC_SLOW_PATH": set on the device by k_transcode, copied to a
     // pinned word behind every transcode; while the copy is in flight the answer is "maybe" and the checked kernel is launched
     uint32_t *d_any_generic = nullptr;
@@ -158,7 +157,7 @@ void free_stream_buffers(pcr_ctx *c)
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); c->transcoded = 0;
-    dfree(c->d_order); dfree(c->d_order_count); dfree(c->d_any_generic); c->order_parity = c->frame_parity = 0;
+    dfree(c->d_order); dfree(c->d_chunk_count); dfree(c->d_any_generic); c->order_stride = 0;
     if (c->any_generic_pending && c->any_generic_ev) (void)hipEventSynchronize(c->any_generic_ev);
     c->any_generic_pending = false;
     if (c->h_any_generic) *c->h_any_generic = 0;
@@ -222,17 +221,10 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
     a.lod = c->d_lod; a.win = c->d_win; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
     a.order = c->d_order;
-    a.order_count = c->d_order_count + 2 * c->frame_parity;
-    a.order_count_next = c->d_order_count + 2 * (c->frame_parity ^ 1);
+    a.chunk_count = c->d_chunk_count;
+    // chunks of the batches this frame draws (the prepass of the frame covered exactly these)
+    a.order_stride = (uint32_t)((a.s.num_batches + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES;
     return a;
-}
-
-// Arguments of a launch that runs the prepass: it counts into the free pair of list counters and zeroes the other one.
-RenderArgs make_prepass_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
-{
-    c->frame_parity = c->order_parity;
-    c->order_parity ^= 1;
-    return make_args(c, p, variant_hqs);
 }
 
 // Does the stream hold a batch for the checked kernel? false only when the device has said so.
@@ -277,7 +269,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
                               c->prepass_win_pixel_bytes == win_pixel_bytes && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
     c->prepass_ready = false;
-    RenderArgs a = have_prepass ? make_args(c, p, variant_hqs) : make_prepass_args(c, p, variant_hqs);
+    RenderArgs a = make_args(c, p, variant_hqs);
     a.win_pixel_bytes = win_pixel_bytes;
     if (!have_prepass) {
         c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
@@ -417,7 +409,8 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB)) || (rc = dalloc_zero(c, c->d_win, nB)) ||
         (rc = dalloc_zero(c, c->d_lane_words, nB * LW_ROWS * PCR_WORKGROUP_SIZE)) || (rc = dalloc_zero(c, c->d_batch_flags, nB)) ||
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE)) ||
-        (rc = dalloc_zero(c, c->d_order, 2 * nB)) || (rc = dalloc_zero(c, c->d_order_count, 4)) || (rc = dalloc_zero(c, c->d_any_generic, 1)) ||
+        (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES)) ||
+        (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS)) || (rc = dalloc_zero(c, c->d_any_generic, 1)) ||
         (c->next_layout == PCR_LAYOUT_POINT_WINDOWS &&
          (rc = dalloc_zero(c, c->d_point_windows, (nB * PW_ROWS + PW_GUARD_ROWS) * PCR_WORKGROUP_SIZE)))) {
         free_stream_buffers(c);
@@ -720,7 +713,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // the prepass sorts batches by what k_transcode found out about them
-    RenderArgs a = make_prepass_args(c, p, method != PCR_METHOD_BASIC);
+    RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "pcr_types.h"
 
 namespace pcr {
@@ -121,14 +122,17 @@ struct RenderArgs {
     uint32_t *lod;            // [nB]
     uint2 *win;               // [nB] LDS depth-window rectangle per batch: {x0 | y0<<16, w | h<<16}, w == 0: none
     pcr_render_stats *stats;  // device: one partial record per prepass workgroup
-    // Dense lists of the batches k_render has to draw, written by the prepass (frustum-culled batches and batches whose
-    // level of detail is zero points are left out): order[0 .. nB) the ordinary ones, order[nB .. 2 nB) those flagged
-    // BF_GENERIC_SLOW_PATH (drawn by the checked variant of the kernel). order_count[kind] = entries of list `kind` for
-    // this frame; order_count_next = the pair the NEXT prepass launch will count into, zeroed by this one (the two pairs
-    // alternate, so no launch is spent on zeroing and nothing is zeroed while it is read: launches of a stream run in order).
-    uint32_t *order;
-    uint32_t *order_count;
-    uint32_t *order_count_next;
+    // Dense lists of the batches k_render has to draw (frustum-culled batches and batches whose level of detail is zero
+    // points are left out), compacted by the prepass in two levels that keep the file's (Morton) order: every prepass
+    // workgroup compacts its PREPASS_BATCHES batches with a wave ballot + prefix count into order[kind][wg * PREPASS_BATCHES ..]
+    // and writes how many there are to chunk_count[kind][wg]; k_render's workgroup x finds its batch with a wave-wide
+    // prefix sum over the chunk counts. kind 0: ordinary batches, kind 1: those flagged BF_GENERIC_SLOW_PATH (drawn by the
+    // checked variant of the kernel). No atomics, nothing to zero between frames. (A first version appended the chunks
+    // with one atomic per workgroup: the chunks then land in arrival order, and the close-up frame, whose heavy batches
+    // lead the file, ran 25 % longer with them shuffled.)
+    uint32_t *order;          // [2][order_stride]
+    uint32_t *chunk_count;    // [2][PCR_MAX_PREPASS_WORKGROUPS]
+    uint32_t order_stride;    // prepass workgroups * PREPASS_BATCHES
     int variant_hqs;          // LOD expression variant
     int win_pixel_bytes;      // what a window pixel of the following k_render<MODE> takes in LDS (WIN_PIXEL_BYTES*)
 };
@@ -155,6 +159,7 @@ __device__ __forceinline__ bool plane_accepts(float x, float y, float z, float w
 // Frame statistics: every prepass workgroup sums its batches in LDS and writes ONE partial record (no global atomics,
 // nothing to zero beforehand); pcr_get_stats adds the partials of the last launch. PCR_STATS_PARTIALS bounds the grid.
 constexpr int PREPASS_THREADS = 256;
+constexpr int PCR_MAX_PREPASS_WORKGROUPS = 2048;        // ceil(65535 batches / 32 batches per prepass workgroup)
 __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_render_stats *partials)
 {
     __shared__ unsigned long long s_sum[4];
@@ -190,7 +195,6 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
     // what k_render has to do for the group's batch: 0 nothing (culled, or no point to draw), 1 draw, 2 draw with the checked variant
     __shared__ uint32_t s_kind[PREPASS_BATCHES];
     if (lane == 0) s_kind[threadIdx.x / PREPASS_LANES] = 0;
-    if (block == 0 && threadIdx.x < 2) a.order_count_next[threadIdx.x] = 0;
     if (b < a.s.num_batches) {
         lod_prepass_batch(a, b, lane, st);                                                       // uniform per 8-lane group
         if (lane == 0) {
@@ -200,21 +204,16 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
         }
     }
     commit_stats(st, a.stats);                              // (barriers inside: s_kind is complete afterwards)
-    // Compaction of the visible batches: one ballot and one prefix count per list in the workgroup's first wave, one
-    // global atomic per workgroup and list. Batches keep their file (Morton) order inside a workgroup's run of
-    // PREPASS_BATCHES; runs land in the order their workgroups get here.
+    // first level of the compaction: one ballot and one prefix count per list, in the workgroup's first wave
     if (threadIdx.x < 64) {
         const uint32_t kind = threadIdx.x < PREPASS_BATCHES ? s_kind[threadIdx.x] : 0u;
         const uint64_t below = (1ull << threadIdx.x) - 1ull;
 #pragma unroll
         for (uint32_t k = 1; k <= 2; ++k) {
             const uint64_t m = __ballot(kind == k);
-            if (m == 0) continue;                           // (wave-uniform)
-            uint32_t base = 0;
-            if (threadIdx.x == 0) base = atomicAdd(&a.order_count[k - 1], (uint32_t)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
+            if (threadIdx.x == 0) a.chunk_count[(k - 1) * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
             if (kind == k)
-                a.order[(size_t)(k - 1) * (size_t)a.s.num_batches + base + (uint32_t)__popcll(m & below)] =
+                a.order[(size_t)(k - 1) * a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] =
                     block * PREPASS_BATCHES + threadIdx.x;
         }
     }
@@ -515,12 +514,46 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int MODE, int LAYOUT, bool GENERIC>
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two workgroups per CU -> <= 64 VGPRs
 {
-    if (blockIdx.x >= a.order_count[GENERIC ? 1 : 0]) return;              // the grid is sized for "every batch visible"
-    const uint32_t b = a.order[(GENERIC ? (size_t)a.s.num_batches : 0) + blockIdx.x];
+    // second level of the compaction: which batch is the blockIdx.x-th of my list? Every wave works it out for itself (a
+    // 64-lane inclusive prefix sum over the chunk counts, 64 chunks = 2048 batches per round): no barrier, no LDS.
+    uint32_t b;
+    {
+        const uint32_t lane = threadIdx.x & 63u, chunks = a.order_stride / PREPASS_BATCHES;
+        const uint32_t *cc = a.chunk_count + (GENERIC ? PCR_MAX_PREPASS_WORKGROUPS : 0);
+        uint32_t before = 0, found = 0xFFFFFFFFu;
+        for (uint32_t c0 = 0; c0 < chunks; c0 += 64) {                      // (uniform)
+            const uint32_t cnt = c0 + lane < chunks ? cc[c0 + lane] : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if ((int)lane >= d) incl += up;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            if (blockIdx.x < before + total) {
+                const uint64_t m = __ballot(before + incl > blockIdx.x);   // first chunk whose inclusive count passes x
+                const uint32_t first = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                const uint32_t excl = __shfl(incl - cnt, first);
+                found = (c0 + first) * PREPASS_BATCHES + (blockIdx.x - before - excl);
+                break;
+            }
+            before += total;
+        }
+        found = __builtin_amdgcn_readfirstlane(found);                      // (the same in every lane: keep it, and the batch index, scalar)
+        if (found == 0xFFFFFFFFu) return;                                   // the grid is sized for "every batch visible"
+        b = a.order[(GENERIC ? (size_t)a.order_stride : 0) + found];
+    }
     const uint32_t lod = a.lod[b];
     const int npr = (int)(lod & LOD_NPR_MASK);
     const bool use_double = (lod & LOD_DOUBLE) != 0;
     const uint32_t tid = threadIdx.x;
+    // (the lambdas below capture these scalars, not the argument block: with `a` captured by reference and the loop body
+    // instantiated five times, hipcc once kept the whole block in scratch memory)
+    uint64_t *const g_fb = a.f.fb, *const g_rg = a.f.rg, *const g_ba = a.f.ba;
+    const int img_w = a.p.width;
+    const uint32_t fb_elems = a.f.fb_elems;
+    const float m00 = a.p.transform[0], m01 = a.p.transform[1], m02 = a.p.transform[2], m03 = a.p.transform[3];
+    const float m10 = a.p.transform[4], m11 = a.p.transform[5], m12 = a.p.transform[6], m13 = a.p.transform[7];
 
     __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
     __shared__ __align__(16) unsigned char s_dyn[DYN_LDS_BYTES];            // escape pool, then the framebuffer window
@@ -656,7 +689,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // (two 16-bit sums per register: a chain adds at most 64 * 255 per channel)
     uint32_t run_pix = NO_PIXEL, run_widx = NO_PIXEL;
     uint32_t run_rg16 = 0, run_bc16 = 0;                    // r << 16 | g,  b << 16 | count
-    auto flush_run = [&]() {
+    auto flush_run = [&]() __attribute__((always_inline)) {
         if (run_pix == NO_PIXEL) return;
         const unsigned long long run_rg = ((unsigned long long)(run_rg16 >> 16) << 32) | (run_rg16 & 0xFFFFu);
         const unsigned long long run_ba = ((unsigned long long)(run_bc16 >> 16) << 32) | (run_bc16 & 0xFFFFu);
@@ -665,15 +698,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             __hip_atomic_fetch_add(&s_rg[run_widx], run_rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&s_ba[run_widx], run_ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            atomicAdd((unsigned long long *)&a.f.rg[run_pix], run_rg);      // :309-310
-            atomicAdd((unsigned long long *)&a.f.ba[run_pix], run_ba);      // :311-312
+            atomicAdd((unsigned long long *)&g_rg[run_pix], run_rg);        // :309-310
+            atomicAdd((unsigned long long *)&g_ba[run_pix], run_ba);        // :311-312
         }
     };
-    auto scatter = [&](uint32_t pix, uint32_t widx, uint32_t depth, uint64_t old, int point) {
+    // `valid`: the pending point is inside the frustum; `off`: ... but outside the batch's LDS window (then `pix` is its pixel
+    // and `old` came from global memory). Both are lane masks the compiler keeps in scalar registers, so choosing between the
+    // LDS and the global path costs no vector instruction. `w`: the window word of the pixel, as a byte offset into s_win
+    // (basic / depth pass) or as an index (colour pass: three planes).
+    auto scatter = [&](bool valid, bool off, uint32_t pix, uint32_t w, uint32_t depth, uint64_t old, int point) __attribute__((always_inline)) {
         if (MODE == MODE_HQS_COLOR) {
             const float pw = __uint_as_float(depth);
             const float old_depth = __uint_as_float((uint32_t)(old >> 32));
-            if ((double)pw <= (double)old_depth * 1.01) {                   // hqs render.cu:296
+            if (valid && (double)pw <= (double)old_depth * 1.01) {          // hqs render.cu:296
                 const uint32_t rgba = bc1_color(pal, (uint32_t)point & 15u);
                 const uint32_t vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);   // r << 16 | g  (rgba = 0x00BBGGRR)
                 const uint32_t vbc = (rgba & 0x00FF0000u) | 1u;                        // b << 16 | 1
@@ -684,19 +721,20 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     run_rg16 += vrg; run_bc16 += vbc;
                 } else {
                     flush_run();
-                    run_pix = pix; run_widx = widx; run_rg16 = vrg; run_bc16 = vbc;
+                    run_pix = pix; run_widx = off ? NO_PIXEL : w; run_rg16 = vrg; run_bc16 = vbc;
                 }
             }
             return;
         }
         // pre-read filter (:297-298) on the depth half only: the result is min(depth<<32|payload) over all inside points
-        // whatever passes it (min is idempotent), so ties go to the atomic instead of a 64-bit compare here. A point that
-        // is not inside carries depth 0xFFFFFFFF: above every real depth, and no pixel index if it slips through an
-        // empty pixel's all-ones word.
-        if (depth > (uint32_t)(old >> 32)) return;
-        const uint64_t key = ((uint64_t)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload);   // :299 / depth.cu:139-145
-        if (widx != NO_PIXEL)      __hip_atomic_fetch_min(&s_win[widx], (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else if (pix != NO_PIXEL)  atomicMin((unsigned long long *)&a.f.fb[pix], (unsigned long long)key);   // :300
+        // whatever passes it (min is idempotent), so ties go to the atomic instead of a 64-bit compare here
+        if (!valid || depth > (uint32_t)(old >> 32)) return;
+#ifdef PCR_EXP_KEY_FILTER
+        if (!((((unsigned long long)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload)) < old)) return;
+#endif
+        const unsigned long long key = ((unsigned long long)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload);   // :299 / depth.cu:139-145
+        if (!off) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_win) + w), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else      atomicMin((unsigned long long *)&g_fb[pix], key);         // :300
     };
 
     // End of a point: SFT0 - sft bits were consumed. Retire the 0..2 words that ran dry, pull in far0/far1 (requested a
@@ -724,12 +762,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         sft = SFT0;                                                                        \
     } while (0)
 
-    constexpr uint32_t NO_DEPTH = 0xFFFFFFFFu;              // "not inside": a NaN for the colour pass's test, the largest key half otherwise
-    uint32_t pend_pix = NO_PIXEL, pend_widx = NO_PIXEL, pend_depth = NO_DEPTH;
+    bool pend_valid = false, pend_off = false;
+    uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
     uint64_t pend_old = 0;
 
     const float *M = a.p.transform;
     const float fw = (float)a.p.width, fh = (float)a.p.height;
+    // Loop constants kept in vector registers on purpose: a v_fma_f32 / v_sub_u32 whose operands are all VGPRs or inline
+    // constants issues in ~2.3 cycles per wave64, the same instruction with an SGPR operand in ~4.2
+    // (tools/exp/instr_rate2.hip). The kernel has the registers to spare (<= 64 for eight waves per SIMD).
+    // (only where there are registers to spare: not in the colour pass, which keeps its run of sums in registers, not with
+    // the packed-words variant's five-word queue, not in the checked variant)
+    constexpr bool VGPR_CONSTANTS = MODE != MODE_HQS_COLOR && LAYOUT == LAYOUT_POINT_WINDOWS && !GENERIC;
+    auto in_vgpr_f = [](float v) { if (!VGPR_CONSTANTS) return v; float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
+    auto in_vgpr_u = [](uint32_t v) { if (!VGPR_CONSTANTS) return v; uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
+    const float m30 = in_vgpr_f(M[12]), m31 = in_vgpr_f(M[13]), m32 = in_vgpr_f(M[14]), m33 = in_vgpr_f(M[15]);   // the w row
+    const uint32_t v_wx0 = in_vgpr_u(wx0), v_wy0 = in_vgpr_u(wy0);
 
     __syncthreads();        // table, escapes and window are visible
 
@@ -740,11 +788,123 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
     uint32_t toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
     uint32_t e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
+
+    // ---- the point loop ---------------------------------------------------------------------------------------------------------
+    // A wave issues in order and the decode is a chain of LDS round trips (table entry -> length -> next key -> next
+    // entry). What can run inside those waits does: the table entry of a symbol is requested one step ahead, the scatter of
+    // the previous point runs under the read for this point's second symbol (-2.5 % kernel time for moving one call), the
+    // framebuffer word of a point is requested a whole point before it is used. A deeper software pipeline (decode k+2 |
+    // project k+1 | scatter k, the projection split over the second and third table read) was built and measured: +4 %,
+    // hipcc spends the 64 registers on copies between the stages (profiles/r02_experiments.md).
+    float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+    float qx = 0.0f, qy = 0.0f, qw = 0.0f;
+    bool candidate = false, w_ok = true, inside = false;
+    int ix = 0, iy = 0;
+
+    // One symbol step (:430-451) of the point being decoded. `e` is the table entry of this symbol, fetched one step ahead;
+    // (bits >> sft) & 0x3FFC is 4 x the 12-bit window of :431-433 (== ((L|R) & mask) >> 20) at the current position, i.e.
+    // the byte offset of an entry. Returns the decoded delta.
+    auto symbol_step = [&]() __attribute__((always_inline)) -> uint32_t {
+        const uint32_t e = e_ahead, toff = toff_ahead;                      // :435-436
+        // :439. The whole entry is subtracted: byte 0 is the length, and only the low six bits of `sft` are ever used (the
+        // 64-bit shift below takes its count modulo 64; 14 <= true sft <= 50) -- a plain v_sub_u32
+        sft -= e;
+        toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
+        e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
+        int32_t val = (int32_t)e >> TE_VALUE_SHIFT;                         // the delta itself (v_ashrrev_i32)
+        if (val == TE_SLOW_VALUE) {                                         // escape or wide
+            if (!GENERIC) {                                                 // every such entry is an escape whose word is in the pool
+                val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
+                sp4 += 4;
+            } else if (e & TE_ESCAPE) {                                     // :438
+                if (sp4 < 4u * esc_lds) {
+                    val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
+                } else {
+                    // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
+                    val = sep_load(sp4 >> 2);
+                    asm volatile("; escape word from global memory %0" : "+v"(val));
+                }
+                sp4 += 4;
+            } else {
+                val = tvalues[toff >> 2];
+                asm volatile("; wide table value from global memory %0" : "+v"(val));
+            }
+        }
+#ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
+        {
+            uint32_t pad = tid;
+#pragma unroll
+            for (int k = 0; k < PCR_EXP_PAD_VALU; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
+        }
+#endif
+        return (uint32_t)val;
+    };
+
+    // first half of rasterize() (:278-287), part 1: the three dot products and the inside test without dividing. For finite
+    // w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1] exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w >
+    // 1 + 2^-24, which rounds above 1); the compare is false for a NaN and for w < 0.
+    auto project_dots = [&]() __attribute__((always_inline)) {
+        qx = __fmaf_rn(m03, 1.0f, __fmaf_rn(m02, fz, __fmaf_rn(m01, fy, m00 * fx)));       // dot4(M + 0, ...)
+        qy = __fmaf_rn(m13, 1.0f, __fmaf_rn(m12, fz, __fmaf_rn(m11, fy, m10 * fx)));       // dot4(M + 4, ...)
+        qw = __fmaf_rn(m33, 1.0f, __fmaf_rn(m32, fz, __fmaf_rn(m31, fy, m30 * fx)));       // dot4(M + 12, ...), operands in VGPRs
+        candidate = fabsf(qx) <= qw && fabsf(qy) <= qw;
+        w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;           // 2^-64 <= w < 2^64
+    };
+    // part 2: the division and the pixel (:279-285). The division is the IEEE sequence hipcc emits for `/` with its range
+    // scaling removed, shared reciprocal, x and y packed; it is bit-identical to `/` for w in [2^-64, 2^64) (no intermediate
+    // leaves the normal range unless |x/w| < 2^-36, where the pixel is the screen centre whatever the last bits are). A
+    // wave in which some candidate's w lies outside that range (or is 0) takes `/` for all lanes.
+    auto project_divide = [&]() __attribute__((always_inline)) {
+        inside = false;
+        if (__builtin_expect(__any(candidate && !w_ok), 0)) {
+            const float nx = qx / qw, ny = qy / qw;
+            if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {   // NaN-rejecting (Appendix C.2)
+                ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);                 // :283-284
+                iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+                inside = (uint32_t)(ix + iy * img_w) < fb_elems;            // :285
+            }
+        } else if (candidate) {
+            const float r0 = __builtin_amdgcn_rcpf(qw);
+            const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
+            const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
+            const v2f q0 = xy * rr;
+            const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
+            const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
+            const v2f half = {0.5f, 0.5f}, size = {fw, fh};
+            const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
+            ix = (int)img.x; iy = (int)img.y;                                       // :284 (the pixel index is always < fb_elems here)
+            inside = true;
+        }
+    };
+    // part 3: the point becomes the pending one; its framebuffer word is requested now and consumed an iteration later:
+    // from the LDS window if the pixel lies in the batch's rectangle (nearly always), from global memory otherwise (:297)
+    auto project_request = [&]() __attribute__((always_inline)) {
+        bool in_window = false, off_window = false;
+        if (inside) {
+            pend_depth = __float_as_uint(qw);                                       // :287
+            if (MODE == MODE_HQS_COLOR) pend_pix = (uint32_t)(ix + iy * img_w);     // the colour pass names its runs by pixel
+            const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
+            in_window = rx < ww && ry < wh;
+            off_window = !in_window;
+            pend_w = MODE == MODE_HQS_COLOR ? ry * ww + rx : (ry * ww + rx) * 8u;
+        }
+        pend_valid = inside;
+        pend_off = off_window;
+        // (two separate steps, the LDS read first: a load into the same registers issued behind it only has to wait for
+        // the LDS counter, the other way round the LDS read would wait for every vector-memory load in flight)
+        if (in_window) pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32
+                                                         : *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(s_win) + pend_w);
+        if (off_window) {
+            pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
+            pend_old = g_fb[pend_pix];
+        }
+    };
+
     for (int seg = 0; seg < npr_run; seg += 16) {
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
-      scatter(pend_pix, pend_widx, pend_depth, pend_old, seg - 1);
-      pend_pix = pend_widx = NO_PIXEL; pend_depth = NO_DEPTH;
+      scatter(pend_valid, pend_off, pend_pix, pend_w, pend_depth, pend_old, seg - 1);
+      pend_valid = false;
       if (MODE != MODE_HQS_DEPTH) {
           pal = bc1_palette(cnext);                     // once per 16 points instead of once per surviving point
           cnext = cblocks[min((seg >> 4) + 1, 3)];
@@ -765,119 +925,38 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const uint32_t extra1 = lw_load((uint32_t)(i + 8) * LW_ROW_BYTES + tid * 4);
 #endif
 #endif
-        uint32_t dec[3];
-        {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {                                   // :430
-                // `e` is the table entry of this symbol, fetched one step ahead; (bits >> sft) & 0x3FFC is 4 x the 12-bit
-                // window of :431-433 (== ((L|R) & mask) >> 20) at the current position, i.e. the byte offset of an entry
-                const uint32_t e = e_ahead, toff = toff_ahead;              // :435-436
-                // :439. The whole entry is subtracted: byte 0 is the length, and only the low six bits of `sft` are ever
-                // used (the 64-bit shift below takes its count modulo 64; 14 <= true sft <= 50) -- a plain v_sub_u32
-                sft -= e;
-                toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
-                e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
-                int32_t val = (int32_t)e >> TE_VALUE_SHIFT;                 // the delta itself (v_ashrrev_i32)
-                if (val == TE_SLOW_VALUE) {                                 // escape or wide
-                    if (!GENERIC) {                                         // every such entry is an escape whose word is in the pool
-                        val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
-                        sp4 += 4;
-                    } else if (e & TE_ESCAPE) {                             // :438
-                        if (sp4 < 4u * esc_lds) {
-                            val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
-                        } else {
-                            // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
-                            val = sep_load(sp4 >> 2);
-                            asm volatile("; escape word from global memory %0" : "+v"(val));
-                        }
-                        sp4 += 4;
-                    } else {
-                        val = tvalues[toff >> 2];
-                        asm volatile("; wide table value from global memory %0" : "+v"(val));
-                    }
-                }
-                dec[j] = (uint32_t)val;
-#ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
-                {
-                    uint32_t pad = tid;
-#pragma unroll
-                    for (int k = 0; k < PCR_EXP_PAD_VALU; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
-                }
-#endif
-            }
-        }
-        px = (int32_t)((uint32_t)px + dec[0]);                              // :454-456, :463
-        py = (int32_t)((uint32_t)py + dec[1]);
-        pz = (int32_t)((uint32_t)pz + dec[2]);
+        const uint32_t d0 = symbol_step();                                  // :430
+        // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
+        // word has been in flight since the end of the last iteration
+        scatter(pend_valid, pend_off, pend_pix, pend_w, pend_depth, pend_old, i - 1);
+        const uint32_t d1 = symbol_step();
+        const uint32_t d2 = symbol_step();
+        px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
+        py = (int32_t)((uint32_t)py + d1);
+        pz = (int32_t)((uint32_t)pz + d2);
         PCR_ADVANCE_WORD_WINDOW();
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
-        if ((px ^ py ^ pz) == 0x7fffffff && i == 63) a.f.fb[tid] = 0;
+        if ((px ^ py ^ pz) == 0x7fffffff && i == 63) g_fb[tid] = 0;
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
         continue;
 #endif
-        // second half of rasterize() for point i-1: its framebuffer word has been in flight during this point's decode.
-        // Done before point i is projected so that the projection can write the pending registers in place.
-        scatter(pend_pix, pend_widx, pend_depth, pend_old, i - 1);
-        float x, y, z;
         if (use_double) {                                                   // :459-461
-            x = (float)__fma_rn((double)px, sx, ox);
-            y = (float)__fma_rn((double)py, sy, oy);
-            z = (float)__fma_rn((double)pz, sz, oz);
+            fx = (float)__fma_rn((double)px, sx, ox);
+            fy = (float)__fma_rn((double)py, sy, oy);
+            fz = (float)__fma_rn((double)pz, sz, oz);
         } else {                                                            // :529-531
-            x = __fmaf_rn((float)px, fsx, fox);
-            y = __fmaf_rn((float)py, fsy, foy);
-            z = __fmaf_rn((float)pz, fsz, foz);
+            fx = __fmaf_rn((float)px, fsx, fox);
+            fy = __fmaf_rn((float)py, fsy, foy);
+            fz = __fmaf_rn((float)pz, fsz, foz);
         }
-
-        // first half of rasterize() (:278-287) for point i
-        const float qx = dot4(M + 0, x, y, z, 1.0f);
-        const float qy = dot4(M + 4, x, y, z, 1.0f);
-        const float qw = dot4(M + 12, x, y, z, 1.0f);
-        uint32_t pix = NO_PIXEL, widx = NO_PIXEL, depth = NO_DEPTH;
-        // Inside test (:296) without dividing: for finite w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1]
-        // exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w > 1 + 2^-24, which rounds above 1). The division
-        // itself is the IEEE sequence hipcc emits for `/` with its range scaling removed, shared reciprocal, x and y
-        // packed; it is bit-identical to `/` for w in [2^-64, 2^64) (no intermediate leaves the normal range unless
-        // |x/w| < 2^-36, where the pixel is the screen centre whatever the last bits are). Anything else takes `/`.
-        const bool w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;        // 2^-64 <= w < 2^64
-        if (__builtin_expect(__any(!w_ok && !(qw <= 0.0f)), 0)) {
-            const float nx = qx / qw, ny = qy / qw;
-            if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {   // NaN-rejecting (Appendix C.2)
-                const int ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);       // :283-284
-                const int iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
-                pix = (uint32_t)(ix + iy * a.p.width);                      // :285
-                if (pix < a.f.fb_elems) {
-                    depth = __float_as_uint(qw);                            // :287
-                    const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
-                    if (rx < ww && ry < wh) widx = ry * ww + rx;
-                } else {
-                    pix = NO_PIXEL;
-                }
-            }
-        } else if (w_ok && fabsf(qx) <= qw && fabsf(qy) <= qw) {
-            const float r0 = __builtin_amdgcn_rcpf(qw);
-            const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
-            const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
-            const v2f q0 = xy * rr;
-            const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
-            const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
-            const v2f half = {0.5f, 0.5f}, size = {fw, fh};
-            const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
-            const int ix = (int)img.x, iy = (int)img.y;                             // :284
-            pix = (uint32_t)(ix + iy * a.p.width);                                  // :285 (always < fb_elems here)
-            depth = __float_as_uint(qw);                                            // :287
-            const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
-            if (rx < ww && ry < wh) widx = ry * ww + rx;
-        }
-
+        project_dots();                                                     // first half of rasterize() (:278-287) for point i
+        project_divide();
 #ifdef PCR_EXP_NO_FBLOAD   /* experiment only: decode + projection, no framebuffer traffic (results are wrong) */
-        if (pix == 0x12345678u || widx == 0x123456u) a.f.fb[tid] = __float_as_uint(qw);
-        continue;
+        if (inside && ix == 0x12345678) g_fb[tid] = __float_as_uint(qw);
+        pend_valid = false;
+#else
+        project_request();
 #endif
-        pend_pix = pix;
-        pend_widx = widx;
-        pend_depth = depth;
-        if (widx != NO_PIXEL)      pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[widx] << 32 : s_win[widx];   // :297 on the LDS copy
-        else if (pix != NO_PIXEL)  pend_old = a.f.fb[pix];                  // :297
         if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
 #ifdef PCR_EXP_EXTRA_LOAD
         asm volatile("; extra load consumed %0" :: "v"(extra0));
@@ -887,7 +966,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
       }
     }
-    scatter(pend_pix, pend_widx, pend_depth, pend_old, npr_run - 1);
+    scatter(pend_valid, pend_off, pend_pix, pend_w, pend_depth, pend_old, npr_run - 1);
     if (MODE == MODE_HQS_COLOR) flush_run();
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
