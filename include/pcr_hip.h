@@ -156,24 +156,31 @@ int pcr_resolve_basic_range(pcr_ctx *ctx, const pcr_render_params *params, const
 int pcr_fence_record(pcr_ctx *ctx, int slot, void *hip_stream);
 int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
 
-/* HBM layout the context gives the next stream it loads (pcr_stream_begin fixes it). Both hold the same bits and decode to
- * the same points; the Huffman decode runs every frame in both.
+/* HBM layout the context gives the next stream it loads (pcr_stream_begin fixes it). All hold the same bits and decode to
+ * the same points; the Huffman decode runs every frame in all of them. Only what the layout's kernel reads is kept: the
+ * raw cluster-interleaved words of the file, the int32/int8 decoder tables and the cluster prefix are released by the first
+ * frame after the last batch was uploaded (pcr_upload_tail has to come before that frame).
  *   PCR_LAYOUT_WORDS          per chain the sequence of 32-bit words it consumes (320 B per chain allocated, ~3 B per
  *                             point read): the decode keeps a five-word queue per lane.
- *   PCR_LAYOUT_POINT_WINDOWS  (default) additionally, per point, the 64 bits of its chain's stream that start at the
- *                             point's first bit (8 B per point): no queue in the decode, ~20 % fewer instructions per
- *                             point for ~2.5x the bytes per frame, on a kernel that is issue bound, not HBM bound. */
+ *   PCR_LAYOUT_POINT_WINDOWS  (default) per point the 64 bits of its chain's stream that start at the point's first bit
+ *                             (8 B per point): no queue in the decode, ~20 % fewer instructions per point for ~2.5x the
+ *                             bytes per frame, on a kernel that is bound by instruction issue and latency, not by HBM.
+ *   PCR_LAYOUT_BOTH           both resident: either decode variant can draw a frame (pcr_set_render_variant). */
 #define PCR_LAYOUT_WORDS 0
 #define PCR_LAYOUT_POINT_WINDOWS 1
+#define PCR_LAYOUT_BOTH 2
 int pcr_set_stream_layout(pcr_ctx *ctx, int layout);
-/* A stream loaded with PCR_LAYOUT_POINT_WINDOWS keeps the packed words too, so either decode variant can draw a frame.
- * AUTO (default): the point-window variant while the image has at most 4096 pixels (one LDS framebuffer window) per loaded
- * batch, the packed-words variant beyond that, where the frame is bound by global framebuffer traffic and the smaller
- * stream wins. WORDS / POINT_WINDOWS force one (the latter only where the windows are resident). Results are identical. */
+/* Which decode variant draws. AUTO (default): the one the stream's layout holds; with PCR_LAYOUT_BOTH the point-window
+ * variant while the image has at most 4096 pixels (one LDS framebuffer window) per loaded batch, the packed-words variant
+ * beyond that, where the frame is bound by global framebuffer traffic and the smaller stream wins. WORDS / POINT_WINDOWS
+ * force one; a render call fails with PCR_E_ARG if the stream's layout does not hold it. Results are identical. */
 #define PCR_VARIANT_AUTO 0
 #define PCR_VARIANT_WORDS 1
 #define PCR_VARIANT_POINT_WINDOWS 2
 int pcr_set_render_variant(pcr_ctx *ctx, int variant);
+/* Device bytes the loaded stream occupies right now (every per-stream allocation of the context, pads and guards included;
+ * framebuffers excluded). Drops when the first frame after the last upload releases what only the load-time transcode reads. */
+int64_t pcr_stream_resident_bytes(const pcr_ctx *ctx);
 
 /* pcr_clear and the cull/LOD prepass of the frame's first render call in ONE launch: equivalent to pcr_clear followed by
  * what pcr_render_basic (method PCR_METHOD_BASIC) or pcr_render_hqs_depth (PCR_METHOD_HQS) would do first. The render call

@@ -18,6 +18,7 @@
 using namespace pcr;
 
 constexpr int PCR_STATS_PARTIALS = PCR_MAX_PREPASS_WORKGROUPS;   // one partial record per prepass workgroup
+constexpr int64_t TRANSCODE_CHUNK = 128;        // batches per k_transcode launch when the lane-major words are scratch (40 MB)
 
 struct pcr_ctx {
     int device = 0;
@@ -62,6 +63,13 @@ struct pcr_ctx {
     int next_layout = PCR_LAYOUT_POINT_WINDOWS;
     int variant = PCR_VARIANT_AUTO;             // which k_render variant draws a stream that has both layouts resident
     int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words / d_point_windows are final
+    // PCR_LAYOUT_POINT_WINDOWS keeps no lane-major words: d_lane_words is then k_transcode's scratch for TRANSCODE_CHUNK
+    // batches at a time (launches of a stream run in order, so consecutive launches may reuse it)
+    bool lane_words_scratch = false;
+    // set by the first frame after the last batch: the buffers only k_transcode reads (raw word stream, int32/int8 tables,
+    // cluster prefix, the scratch) have been released; pcr_upload_tail is refused from then on
+    bool finalized = false;
+    size_t stream_bytes = 0;                    // device bytes the loaded stream occupies right now (pcr_stream_resident_bytes)
     pcr_render_stats *d_stats = nullptr;        // PCR_STATS_PARTIALS partial records, one per prepass workgroup
     int stats_partials = 0;                     // how many the last render launch wrote
     // pinned staging arenas of the loader (double-buffered)
@@ -162,6 +170,7 @@ void free_stream_buffers(pcr_ctx *c)
     c->any_generic_pending = false;
     if (c->h_any_generic) *c->h_any_generic = 0;
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0; c->prepass_ready = false;
+    c->finalized = false; c->lane_words_scratch = false; c->stream_bytes = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
 
@@ -178,12 +187,19 @@ void free_frame_buffers(pcr_ctx *c)
     c->fb = c->rg = c->ba = nullptr; c->fb_elems = 0; c->width = c->height = 0;
 }
 
-template <class T> int dalloc_zero(pcr_ctx *c, T *&p, size_t count)
+template <class T> int dalloc_zero(pcr_ctx *c, T *&p, size_t count, size_t *account = nullptr)
 {
     size_t bytes = (count ? count : 1) * sizeof(T);
     HIP_TRY(c, hipMalloc((void **)&p, bytes));
     HIP_TRY(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    if (account) *account += bytes;
     return PCR_OK;
+}
+template <class T> void dfree_counted(pcr_ctx *c, T *&p, size_t count)
+{
+    if (!p) return;
+    c->stream_bytes -= (count ? count : 1) * sizeof(T);
+    dfree(p);
 }
 
 int check_params(pcr_ctx *c, const pcr_render_params *p)
@@ -244,15 +260,37 @@ void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
     const int64_t final_end = loaded == c->hdr.num_batches ? loaded : loaded - 1;
     const int64_t end = include_provisional ? loaded : final_end;
     if (end > c->transcoded) {
-        hipLaunchKernelGGL(k_transcode, dim3((unsigned)(end - c->transcoded)), dim3(PCR_WORKGROUP_SIZE), 0, st,
-                           make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows,
-                           c->d_any_generic, (int)c->transcoded);
+        for (int64_t b0 = c->transcoded; b0 < end; ) {
+            const int64_t n = c->lane_words_scratch ? std::min(TRANSCODE_CHUNK, end - b0) : end - b0;
+            hipLaunchKernelGGL(k_transcode, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
+                               make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows,
+                               c->d_any_generic, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
+            b0 += n;
+        }
         c->transcoded = std::max(c->transcoded, final_end);
         // the sticky "some batch needs the checked kernel" word follows every transcode to the host
         (void)hipMemcpyAsync(c->h_any_generic, c->d_any_generic, 4, hipMemcpyDeviceToHost, st);
         (void)hipEventRecord(c->any_generic_ev, st);
         c->any_generic_pending = true;
     }
+}
+
+// Once the whole stream is loaded and every batch has its final transcode, what only k_transcode reads is dead weight:
+// the raw cluster-interleaved words (the largest array of the file), the int32 / int8 decoder tables (k_render reads the
+// packed entries; the int32 values stay if some batch has `wide` entries), the cluster prefix and the transcode scratch.
+// Called from the first frame after completion; hipFree waits for the device, once.
+void maybe_finalize(pcr_ctx *c)
+{
+    if (c->finalized || c->batches_loaded != c->hdr.num_batches || c->transcoded != c->batches_loaded) return;
+    if (c->async_upload && (!c->loader_tasks.empty() || c->batches_resident != c->batches_loaded)) return;   // the loader stream is still at it
+    if (c->any_generic_pending) { (void)hipEventSynchronize(c->any_generic_ev); c->any_generic_pending = false; }
+    const size_t nB = (size_t)c->hdr.num_batches;
+    dfree_counted(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS);
+    dfree_counted(c, c->d_table_lens, nB * 4096);
+    dfree_counted(c, c->d_cluster_sizes, nB * 32);
+    if (*c->h_any_generic == 0) dfree_counted(c, c->d_table_values, nB * 4096);
+    if (c->lane_words_scratch) dfree_counted(c, c->d_lane_words, (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB) * LW_ROWS * PCR_WORKGROUP_SIZE);
+    c->finalized = true;
 }
 
 template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
@@ -264,6 +302,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     c->last_frame_batches = nB;
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
+    maybe_finalize(c);
     const int win_pixel_bytes = MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
     const int variant_hqs = MODE != MODE_BASIC;
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
@@ -278,12 +317,16 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
     if (timed) HIP_TRY(c, hipEventRecord(c->kt_begin[slot], c->stream));
-    // With the point windows resident both variants can draw the frame (the packed words stay in HBM). The windows
-    // variant trades bytes for instructions, which pays while the scatter runs in the LDS framebuffer windows; when the
-    // batches' rectangles outgrow those (more pixels per batch than a window holds: 4096x4096 over 1526 batches), the frame
-    // is bound by global framebuffer traffic and the 3 B per point of the packed words win (0.70 ms against 0.75 ms).
-    const bool windows = c->layout == PCR_LAYOUT_POINT_WINDOWS && c->variant != PCR_VARIANT_WORDS &&
-                         (c->variant == PCR_VARIANT_POINT_WINDOWS || (int64_t)c->width * c->height <= nB * (int64_t)WIN_PIXELS);
+    // A stream loaded with PCR_LAYOUT_BOTH can be drawn by either variant. The windows variant trades bytes for
+    // instructions, which pays while the scatter runs in the LDS framebuffer windows; when the batches' rectangles outgrow
+    // those (more pixels per batch than a window holds: 4096x4096 over 1526 batches), the frame is bound by global
+    // framebuffer traffic and the 3 B per point of the packed words win.
+    const bool have_windows = c->layout != PCR_LAYOUT_WORDS, have_words = c->layout != PCR_LAYOUT_POINT_WINDOWS;
+    if ((c->variant == PCR_VARIANT_WORDS && !have_words) || (c->variant == PCR_VARIANT_POINT_WINDOWS && !have_windows))
+        return set_err(c, PCR_E_ARG, "render variant %d needs a stream loaded with that layout (or PCR_LAYOUT_BOTH); this one has layout %d",
+                       c->variant, c->layout);
+    const bool windows = have_windows && (c->variant == PCR_VARIANT_POINT_WINDOWS || !have_words ||
+                                          (c->variant == PCR_VARIANT_AUTO && (int64_t)c->width * c->height <= nB * (int64_t)WIN_PIXELS));
     // The grid is sized for "every batch visible"; workgroups beyond the prepass's dense list return at once. The checked
     // kernel (second list) is launched only if the stream may hold a flagged batch.
     const bool generic = maybe_generic_batches(c);
@@ -402,17 +445,22 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
     c->enc_words = h->encoded_bytes / 4 + PCR_ENCODED_PAD_WORDS;      // HuffmanLasLoader.cpp:39-41
     c->sep_words = h->separate_bytes / 4 + PCR_SEPARATE_PAD_WORDS;
     int rc;
-    if ((rc = dalloc_zero(c, c->d_batches, nB)) || (rc = dalloc_zero(c, c->d_start, nB * 3072)) ||
-        (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS)) || (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words + PCR_GUARD_WORDS)) ||
-        (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096)) ||
-        (rc = dalloc_zero(c, c->d_table_lens, nB * 4096)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32)) ||
-        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH)) || (rc = dalloc_zero(c, c->d_lod, nB)) || (rc = dalloc_zero(c, c->d_win, nB)) ||
-        (rc = dalloc_zero(c, c->d_lane_words, nB * LW_ROWS * PCR_WORKGROUP_SIZE)) || (rc = dalloc_zero(c, c->d_batch_flags, nB)) ||
-        (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE)) ||
-        (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES)) ||
-        (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS)) || (rc = dalloc_zero(c, c->d_any_generic, 1)) ||
-        (c->next_layout == PCR_LAYOUT_POINT_WINDOWS &&
-         (rc = dalloc_zero(c, c->d_point_windows, (nB * PW_ROWS + PW_GUARD_ROWS) * PCR_WORKGROUP_SIZE)))) {
+    size_t *acc = &c->stream_bytes;
+    const bool windows = c->next_layout != PCR_LAYOUT_WORDS, words = c->next_layout != PCR_LAYOUT_POINT_WINDOWS;
+    c->lane_words_scratch = !words;
+    const size_t lw_batches = words ? nB : (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB);
+    if ((rc = dalloc_zero(c, c->d_batches, nB, acc)) || (rc = dalloc_zero(c, c->d_start, nB * 3072, acc)) ||
+        (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS, acc)) ||
+        (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words + PCR_GUARD_WORDS, acc)) ||
+        (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024, acc)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096, acc)) ||
+        (rc = dalloc_zero(c, c->d_table_lens, nB * 4096, acc)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32, acc)) ||
+        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) || (rc = dalloc_zero(c, c->d_lod, nB, acc)) ||
+        (rc = dalloc_zero(c, c->d_win, nB, acc)) ||
+        (rc = dalloc_zero(c, c->d_lane_words, lw_batches * LW_ROWS * PCR_WORKGROUP_SIZE, acc)) || (rc = dalloc_zero(c, c->d_batch_flags, nB, acc)) ||
+        (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
+        (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES, acc)) ||
+        (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
+        (windows && (rc = dalloc_zero(c, c->d_point_windows, (nB * PW_ROWS + PW_GUARD_ROWS) * PCR_WORKGROUP_SIZE, acc)))) {
         free_stream_buffers(c);
         return rc;
     }
@@ -580,6 +628,10 @@ int pcr_upload_tail(pcr_ctx *c, const uint32_t *enc, size_t n_enc, const int32_t
     if (!c) return PCR_E_ARG;
     c->prepass_ready = false;        // what pcr_frame_begin prepared no longer matches the context's state
     if (!c->stream_open) return set_err(c, PCR_E_ARG, "no stream");
+    if (c->finalized) {
+        if (n_enc == 0 && n_sep == 0) return PCR_OK;
+        return set_err(c, PCR_E_ARG, "the stream was finalised by a frame (raw words released): upload the shard tail before the first render call");
+    }
     if (n_enc > PCR_ENCODED_PAD_WORDS || n_sep > PCR_SEPARATE_PAD_WORDS)
         return set_err(c, PCR_E_ARG, "tail larger than the pads (%d / %d words)", PCR_ENCODED_PAD_WORDS, PCR_SEPARATE_PAD_WORDS);
     if ((size_t)(c->enc_words - c->enc_ptr) < n_enc || (size_t)(c->sep_words - c->sep_ptr) < n_sep)
@@ -610,7 +662,8 @@ int pcr_stream_unload(pcr_ctx *c)
 int pcr_set_stream_layout(pcr_ctx *c, int layout)
 {
     if (!c) return PCR_E_ARG;
-    if (layout != PCR_LAYOUT_WORDS && layout != PCR_LAYOUT_POINT_WINDOWS) return set_err(c, PCR_E_ARG, "unknown stream layout %d", layout);
+    if (layout != PCR_LAYOUT_WORDS && layout != PCR_LAYOUT_POINT_WINDOWS && layout != PCR_LAYOUT_BOTH)
+        return set_err(c, PCR_E_ARG, "unknown stream layout %d", layout);
     c->next_layout = layout;         // the stream that is loaded keeps the layout it was loaded with
     return PCR_OK;
 }
@@ -653,6 +706,8 @@ int64_t pcr_batches_resident(pcr_ctx *c)
     return c->visible_batches();
 }
 int64_t pcr_points_loaded(const pcr_ctx *c) { return c ? c->points_loaded : 0; }
+
+int64_t pcr_stream_resident_bytes(const pcr_ctx *c) { return c && c->stream_open ? (int64_t)c->stream_bytes : 0; }
 
 int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
 {
@@ -713,6 +768,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // the prepass sorts batches by what k_transcode found out about them
+    maybe_finalize(c);
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);

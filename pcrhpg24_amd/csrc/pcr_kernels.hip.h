@@ -396,7 +396,7 @@ __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lby
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
                                                                   uint32_t *packed_table, uint2 *point_windows,
-                                                                  uint32_t *any_generic, int first_batch)
+                                                                  uint32_t *any_generic, int first_batch, int lane_words_first)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     const uint32_t cluster = tid >> 5, lane32 = tid & 31u, half_shift = tid & 32u, lanes_below = (1u << lane32) - 1u;
     const uint32_t cbase = cluster ? (uint32_t)s.cluster_sizes[(size_t)b * 32 + cluster - 1] : 0u;   // :407-410
     uint32_t *ring = s_ring + cluster * RING_WORDS;
-    uint32_t *out = lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE + tid;
+    uint32_t *out = lane_words + (size_t)(b - (uint32_t)lane_words_first) * LW_ROWS * PCR_WORKGROUP_SIZE + tid;   // resident, or the launch's scratch
     uint32_t row = 2;
     uint64_t bits = ((uint64_t)enc_load(cbase + lane32) << 32) | enc_load(cbase + 32 + lane32);   // :416-417
     out[0] = (uint32_t)(bits >> 32);

@@ -306,6 +306,11 @@ class Context:
 
     # method side
     # -- GPU encoder (include/pcr_gpu_encode.h) ---------------------------------------------------------
+    @property
+    def resident_bytes(self) -> int:
+        """Device bytes the loaded stream occupies right now (pcr_stream_resident_bytes)."""
+        return int(self.lib.pcr_stream_resident_bytes(self.h))
+
     def gpu_encode_points(self, x, y, z, color, las: LasInfo, morton_sort: bool = True, chunk_points: int = 0,
                           pad_tails: bool = False) -> tuple[NativeBytes, dict]:
         """The encoder of `encode_points`, run on the GPU; same file image byte for byte."""
@@ -418,7 +423,7 @@ class Context:
     def flip_sign(self):
         self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
 
-    LAYOUT_WORDS, LAYOUT_POINT_WINDOWS = 0, 1
+    LAYOUT_WORDS, LAYOUT_POINT_WINDOWS, LAYOUT_BOTH = 0, 1, 2
 
     def set_stream_layout(self, layout: int) -> None:
         """HBM layout of the next stream this context loads (pcr_hip.h: PCR_LAYOUT_*)."""

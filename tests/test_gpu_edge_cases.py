@@ -41,6 +41,8 @@ def load(ctx, image):
 @pytest.fixture(params=["point_windows", "words"])
 def ctx(request):
     c = P.Context(0)
+    if request.param == "words":
+        c.set_stream_layout(P.Context.LAYOUT_BOTH)      # both layouts resident, the packed-words kernel forced
     c.set_render_variant(P.Context.VARIANT_POINT_WINDOWS if request.param == "point_windows" else P.Context.VARIANT_WORDS)
     yield c
     c.close()
@@ -216,3 +218,36 @@ def test_async_loader_with_shard_tail(ctx):
         assert np.array_equal(ctx.read_framebuffer(full=True), ofb)
     finally:
         ctx.set_async_upload(False)
+
+
+def test_first_frame_releases_what_only_the_transcode_reads():
+    """ADVICE r01 / VERDICT item 4: a context keeps only what its layout's kernel reads. The raw word stream, the int32/int8
+    tables and the cluster prefix go with the first frame after the last upload; the default layout holds no lane-major
+    words at all; a shard tail has to arrive before that frame."""
+    nb, st = P.synth_encode(100_000_000, scenes.SEED, 0, 655_360, 6_553_600, 4)     # ten batches of the benchmark stream
+    f = P.HuffmanFile(nb.view())
+    of = oracle.OracleFile(nb.view())
+    p = scenes.with_flags(scenes.cameras(640, 360)["overview"], lod_percent=100, cull=0)
+    sizes = {}
+    for name, layout in (("point_windows", P.Context.LAYOUT_POINT_WINDOWS), ("words", P.Context.LAYOUT_WORDS), ("both", P.Context.LAYOUT_BOTH)):
+        c = P.Context(0)
+        try:
+            c.set_image_size(640, 360)
+            c.set_stream_layout(layout)
+            load(c, nb.view())
+            before = c.resident_bytes
+            c.clear(); c.render_basic(p)
+            fb = c.read_framebuffer(full=True)
+            after = c.resident_bytes
+            assert np.array_equal(fb, of.render_basic(p)[0])
+            assert after < before                       # raw words + tables released
+            c.clear(); c.render_basic(p)                # and nothing that was released is needed again
+            assert np.array_equal(c.read_framebuffer(full=True), fb)
+            with pytest.raises(P.PcrError, match="finalised"):
+                c.upload_tail(np.ones(4, np.uint32), np.zeros(0, np.int32))
+            c.upload_tail(np.zeros(0, np.uint32), np.zeros(0, np.int32))      # an empty tail is a no-op
+            sizes[name] = after / (f.numBatches * 65536)
+        finally:
+            c.close()
+    # bytes per point resident: windows 8 + side data; words 5 (80 rows of 4 B per 64 points) + side data
+    assert sizes["point_windows"] < 9.6 and sizes["words"] < 6.6 and sizes["both"] > sizes["point_windows"] + 4.9

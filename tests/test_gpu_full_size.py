@@ -28,6 +28,7 @@ def whole(big):
     image, hf, of = big
     ctx = P.Context(0)
     ctx.set_image_size(W, H)
+    ctx.set_stream_layout(P.Context.LAYOUT_BOTH)        # test_both_decode_variants_agree_at_full_size draws with either
     ctx.stream_begin(hf.header(), 0)
     for b0 in range(0, hf.numBatches, 100):
         ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
@@ -72,7 +73,7 @@ def test_hqs_passes_equal_oracle_at_full_size(big, whole):
 
 
 def test_both_decode_variants_agree_at_full_size(whole):
-    """The stream is resident in both layouts; the packed-words variant (what PCR_VARIANT_AUTO picks for large images)
+    """The stream is resident in both layouts (PCR_LAYOUT_BOTH); the packed-words variant (what PCR_VARIANT_AUTO picks for large images)
     and the point-window variant draw bit-identical frames, basic and HQS, for both cameras."""
     try:
         for cam in ("overview", "closeup"):

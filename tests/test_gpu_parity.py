@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 W, H = 640, 360
 
 
-# Every test of this module runs once per decode variant: "point_windows" (the default layout's own kernel), "words" on
-# the same resident stream (what PCR_VARIANT_AUTO picks for images with few batches per pixel, as here), and "words_only"
+# Every test of this module runs once per decode variant: "point_windows" (the default layout's own kernel), "words" on a
+# stream loaded with PCR_LAYOUT_BOTH (what PCR_VARIANT_AUTO then picks for images with few batches per pixel), and "words_only"
 # on a stream loaded with PCR_LAYOUT_WORDS (no point windows in HBM at all).
 @pytest.fixture(scope="module", params=["point_windows", "words", "words_only"])
 def renderer(request):
@@ -19,6 +19,8 @@ def renderer(request):
     if request.param == "words_only":
         r.ctx.set_stream_layout(P.Context.LAYOUT_WORDS)
     else:
+        if request.param == "words":
+            r.ctx.set_stream_layout(P.Context.LAYOUT_BOTH)
         r.ctx.set_render_variant(P.Context.VARIANT_POINT_WINDOWS if request.param == "point_windows" else P.Context.VARIANT_WORDS)
     yield r
     r.ctx.close()
