@@ -5,13 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): 1e8 synthetic Morton-sorted points, per-batch Huffman-compressed
-(1526 batches), 1920x1080, basic {depth,colour} atomicMin raster, LOD% = 100 and frustum culling off so
-every point is decoded and rasterized. For N > 1 the scene grows to N x 1e8 points (weak
-scaling), chunks are sharded contiguously over the ranks and every step ends with the merge of the partial
-framebuffers over RCCL: by default an all-to-all of 1/N slices, a local min + resolve of the slice each rank owns and an
-all-gather of the image (--merge reduce: one min-reduce of the whole frame to rank 0, resolved there; --merge allreduce).
+Workload at N = 1 (BASELINE.json configs[1]): 1e8 synthetic Morton-sorted points, per-batch Huffman-compressed
+(1526 batches), 1920x1080, basic {depth,colour} atomicMin raster, LOD% = 100 and frustum culling off so every point is
+decoded and rasterized, stream resident in HBM in the context's default layout (point windows).
+At N > 1 (configs[3]): 2e9 points in total, chunks sharded contiguously over the ranks (strong scaling over N = 2, 4, 8;
+--points P makes it P points per GPU instead), every step ending with the merge of the partial framebuffers over RCCL:
+by default a min-reduce of the u64 frame to the display rank (--merge a2a / allreduce: the other forms).
 A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM.
+Before the W warm-up steps the frame loop runs for --preroll seconds (not counted as warm-up, not timed): the clocks of a
+fresh box settle in that time, so a 20-step run reports what a 200-step run reports.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -19,6 +21,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,6 +30,8 @@ sys.path.insert(0, ROOT)
 
 CHUNK = 6553600
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+POINTS_ONE_GPU = 100_000_000       # BASELINE.json configs[1]
+POINTS_NODE = 2_000_000_000        # BASELINE.json configs[3]: the whole node's stream at N > 1
 
 
 def parse_args():
@@ -34,18 +39,23 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
+    ap.add_argument("--preroll", type=float, default=1.5, help="seconds of untimed frames before the warm-up steps (clock settling)")
+    ap.add_argument("--points", type=int, default=0, help="points per GPU; 0 = 1e8 on one GPU, 2e9 / N on N > 1 GPUs")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--method", choices=["basic", "hqs"], default="basic")
     ap.add_argument("--lod", type=int, default=100, help="LOD percent (uPointFormat); 100 = all 64 points per chain")
     ap.add_argument("--cull", type=int, default=0)
     ap.add_argument("--camera", choices=["overview", "closeup"], default="overview")
-    ap.add_argument("--merge", choices=["reduce", "allreduce", "a2a"], default="a2a",
+    ap.add_argument("--layout", choices=["point_windows", "words"], default="point_windows",
+                    help="HBM layout of the resident stream = decode variant of the timed steps (pcr_set_stream_layout)")
+    ap.add_argument("--merge", choices=["reduce", "allreduce", "a2a"], default="reduce",
                     help="multi-GPU exchange of the basic method: min-reduce the partial framebuffers to rank 0 (the display "
                          "rank), all-reduce them, or all-to-all slices + local min/resolve + all-gather of the image")
+    ap.add_argument("--pipelined", action="store_true", help="N > 1: merge of frame k on a second stream under the render of frame k+1")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the second pass with the other stream layout")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="keep the per-launch kernel events out of the timed steps (A/B of their overhead)")
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = automatic (bounded)")
@@ -58,6 +68,23 @@ def camera(P, name, w, h):
     if name == "overview":     # camera A: whole tile in the frustum
         return P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h)
     return P.camera_orbit(-1.68, -0.39, 70.0, (300.0, 20.0, 45.0), w, h)   # camera B: close-up, heavy overdraw
+
+
+def load_traffic(P, args):
+    """HBM bytes per k_render launch from the committed PMC profile, per variant -- quoted only if the profile was taken on
+    this kernel version and this workload (it is not measured by this run: the counters need rocprofv3 passes of their own)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return {}, "no profile"
+    ver = P.kernel_version()
+    if t.get("kernel_version") != ver:
+        return {}, "profiles/pmc_traffic_latest.json is for kernel %s, this library is %s: not quoted" % (t.get("kernel_version"), ver)
+    if (t.get("points"), t.get("method"), t.get("width"), t.get("lod"), t.get("cull"), t.get("camera")) != \
+            (args.points, args.method, args.width, args.lod, args.cull, args.camera):
+        return {}, "profiles/pmc_traffic_latest.json is for another workload: not quoted"
+    return t.get("hbm_bytes_per_launch", {}), "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, kernel %s; not measured by this run)" % ver
 
 
 def main():
@@ -80,7 +107,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # PCR_FORCE_DIST=1 exercises the multi-GPU code path (torch-owned int64-mergeable framebuffers, shared stream,
-    # RCCL all-reduce) with a single rank, which is all a one-GPU box can run
+    # RCCL collective) with a single rank, which is all a one-GPU box can run
     use_dist = world > 1 or os.environ.get("PCR_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -90,7 +117,10 @@ def main():
     nthreads = args.threads or min(os.cpu_count() or 8, 16)
 
     # ---- synthetic input: this rank's contiguous range of chunks of the global scene -------------------------
-    total_points = args.points * world
+    fixed_total = args.points == 0 and world > 1           # BASELINE configs[3]: 2e9 points over the node, whatever N is
+    if args.points == 0:
+        args.points = POINTS_ONE_GPU if world == 1 else POINTS_NODE // world
+    total_points = POINTS_NODE if fixed_total else args.points * world
     nchunks = -(-total_points // CHUNK)
     c0, cn = pdist.shard_range(nchunks, world, rank)
     first = c0 * CHUNK
@@ -100,27 +130,34 @@ def main():
     t_gen = time.time() - t0
     hf = P.HuffmanFile(image)
 
-    # ---- load into HBM ----------------------------------------------------------------------------------------
     ctx = P.Context(local_rank)
     ctx.set_image_size(args.width, args.height)
-    t0 = time.time()
-    ctx.stream_begin(hf.header(), 0)
-    for b0 in range(0, hf.numBatches, 100):          # loader tasks of <= 100 records, as HuffmanLasData::process
-        ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
-    if world > 1:
-        # shard boundary: the words that follow this shard in the global stream
-        nxt = pdist.exchange_shard_heads(*hf.head_words(0), dev)
-        if nxt is not None:
-            ctx.upload_tail(*nxt)
-    ctx.synchronize()
-    t_load = time.time() - t0
-
     p = camera(P, args.camera, args.width, args.height)
     p.lod_percent = args.lod
     p.enable_frustum_culling = args.cull
+    LAYOUTS = {"point_windows": P.Context.LAYOUT_POINT_WINDOWS, "words": P.Context.LAYOUT_WORDS}
+
+    def load(layout):
+        """Stream -> HBM in the given layout (loader tasks of <= 100 records, as HuffmanLasData::process)."""
+        if ctx.batches_loaded:
+            ctx.stream_unload()
+        ctx.set_stream_layout(LAYOUTS[layout])
+        t0 = time.time()
+        ctx.stream_begin(hf.header(), 0)
+        for b0 in range(0, hf.numBatches, 100):
+            ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
+        if world > 1:
+            # shard boundary: the words that follow this shard in the global stream (SURVEY B.4)
+            nxt = pdist.exchange_shard_heads(*hf.head_words(0), dev)
+            if nxt is not None:
+                ctx.upload_tail(*nxt)
+        ctx.synchronize()
+        return time.time() - t0
+
+    t_load = load(args.layout)
 
     frame, pipe = None, None
-    if use_dist and args.method == "basic" and os.environ.get("PCR_NO_OVERLAP") != "1":
+    if use_dist and args.method == "basic" and args.pipelined:
         pipe = pdist.PipelinedBasicRenderer(ctx, args.width, args.height, dev, merge=args.merge)   # merge of frame k overlaps render k+1
         step = lambda: pipe.step(p)
     else:
@@ -141,27 +178,57 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # first frame reported separately (one-time costs: code object upload, first launches); the lane-major transcode
-    # itself is part of loading (pcr_upload_batches) and inside load_s
-    fence()
-    t0 = time.perf_counter()
-    step()
-    fence()
-    first_frame_ms = 1e3 * (time.perf_counter() - t0)
-    for _ in range(max(0, args.warmup - 1)):
-        step()
-    fence()
     launches_per_step = 1 if args.method == "basic" else 2
-    ctx.kernel_timing(0 if args.no_kernel_events else max(1, args.steps * launches_per_step // 64) | 1)   # odd: samples both HQS passes
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def timed_run(steps, warmup, preroll_s, kernel_events=True):
+        """(elapsed seconds of `steps` steps between fences, average k_render ms, launches timed, first-frame ms)."""
+        fence()
+        t0 = time.perf_counter()
         step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if args.no_kernel_events:       # A/B of the event overhead: time the kernel in a second, untimed pass instead
-        ctx.kernel_timing(True)
-        for _ in range(min(args.steps, 64)):
+        fence()
+        first_ms = 1e3 * (time.perf_counter() - t0)   # one-time costs: code object upload, release of the load-time buffers
+        # clock pre-roll: frames until the wall clock says so (every rank runs the same count: rank 0 decides)
+        if preroll_s > 0:
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                for _ in range(50):
+                    step()
+                n += 50
+                ctx.synchronize()
+                go_on = torch.tensor([1 if time.perf_counter() - t0 < preroll_s else 0], device=dev)
+                if use_dist:
+                    dist.broadcast(go_on, 0)
+                if not int(go_on.item()):
+                    break
+        for _ in range(warmup):
             step()
+        fence()
+        ctx.kernel_timing((max(1, steps * launches_per_step // 64) | 1) if kernel_events else 0)   # odd: samples both HQS passes
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if not kernel_events:       # A/B of the event overhead: time the kernel in a second, untimed pass instead
+            ctx.kernel_timing(True)
+            for _ in range(min(steps, 64)):
+                step()
+            fence()
+        kernel_ms, launches = ctx.kernel_timing_read()
+        ctx.kernel_timing(False)
+        return elapsed, kernel_ms, launches, first_ms
+
+    elapsed, kernel_ms, kernel_launches, first_frame_ms = timed_run(args.steps, args.warmup, args.preroll, not args.no_kernel_events)
+
+    # distribution of single steps (after the timed region, each step between its own event pair and a sync: launch gaps
+    # included, pipelining across steps excluded)
+    step_ms = []
+    if pipe is None:
+        for _ in range(48):
+            ctx.timing_begin()
+            step()
+            step_ms.append(ctx.timing_end())
         fence()
 
     st = ctx.stats()            # counters of the last render launch (per rank)
@@ -178,30 +245,33 @@ def main():
     # ---- dominant kernel: per-launch HIP event pairs recorded inside pcr_render_* on the context's stream, around
     # k_render only, during the timed steps above (pcr_kernel_timing_*; a stride keeps it to <=64 pairs spread over the
     # whole timed region, since an event pair costs ~5 us of stream time) ---------------------------------------------
-    kernel_ms, kernel_launches = ctx.kernel_timing_read()
-    ctx.kernel_timing(False)
     alg_bytes = ctx.algorithmic_bytes                      # decode-pass bytes of this rank's shard (SURVEY 8d B_dec * points)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            t = json.load(open(tpath))
-            if t.get("points") == args.points and t.get("method") == args.method and t.get("width") == args.width:
-                traffic = t.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic_by_variant, traffic_source = load_traffic(P, args) if world == 1 else ({}, "not quoted for N > 1")
+    resident_main = ctx.resident_bytes
     hbm_read, hbm_copy = ctx.measure_hbm(2 << 30, 5) if rank == 0 else (0.0, 0.0)   # practical ceiling of this box
+    kernel_name = "k_render<%s, %s>" % ("basic" if args.method == "basic" else "hqs_depth + hqs_color",
+                                        "point windows" if args.layout == "point_windows" else "packed words")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_by_variant.get(args.layout), "traffic_source": traffic_source,
                 "peak_measured": {"stream_read": round(hbm_read, 1), "stream_copy": round(hbm_copy, 1), "unit": "GB/s",
                                   "frac_of_read": round(achieved / hbm_read, 5) if hbm_read else None},
-                "kernel": "k_render<%s>" % ("basic" if args.method == "basic" else "hqs_depth+hqs_color"),
+                "kernel": kernel_name, "kernel_version": P.kernel_version(),
                 "kernel_ms": round(kernel_ms, 4), "kernel_launches_timed": kernel_launches, "algorithmic_bytes": alg_bytes,
                 "bytes_per_point": round(alg_bytes / max(1, st["points_iterated"]), 4)}
 
+    def variant_record(layout, ms_step, k_ms, resident):
+        tr = traffic_by_variant.get(layout)
+        return {"ms_per_step": round(ms_step, 4), "kernel_ms": round(k_ms, 4),
+                "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "Mpoints_per_s": round(points_per_step / (ms_step * 1e-3) / 1e6, 1),
+                "resident_bytes_per_point": round(resident / max(1, hf.numPoints), 3),
+                "hbm_bytes_read_per_point": round(tr / max(1, st["points_iterated"]), 3) if tr else None}
+
+    variants = {args.layout: variant_record(args.layout, ms_per_step, kernel_ms, resident_main)}
+
     # ---- CPU baseline + full-size parity check (rank 0, N == 1 only) ----------------------------------------
-    cpu_baseline, parity = None, None
+    cpu_baseline, parity, ties = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
         from tests import oracle
@@ -227,6 +297,18 @@ def main():
         if sample == nb:        # same inputs end to end: compare the whole framebuffer, bit for bit
             ctx.clear(); (ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth)(p)
             parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb))
+        if args.method == "basic" and sample == nb and os.environ.get("PCR_BENCH_TIES") == "1":
+            # pixels whose winning depth several points share, and those where the tied points differ in colour (there the
+            # reference's own result depends on thread order); single-threaded second walk: ~2 min at 1e8
+            a, b = of.count_depth_ties(p, ofb)
+            ties = {"depth_tie_pixels": a, "depth_tie_pixels_other_colour": b}
+
+    # ---- the other layout, same stream, same camera: a shorter second pass (N == 1 only) ---------------------------
+    if world == 1 and not use_dist and not args.no_variants:
+        other = "words" if args.layout == "point_windows" else "point_windows"
+        load(other)
+        e2, k2, _, _ = timed_run(min(args.steps, 100), args.warmup, min(args.preroll, 0.3))
+        variants[other] = variant_record(other, 1e3 * e2 / min(args.steps, 100), k2, ctx.resident_bytes)
 
     if args.method == "hqs":
         merge_desc = "min all-reduce of the depth + sum %s of the colour sums" % ("all-reduce" if args.merge == "allreduce" else "reduce to rank 0")
@@ -234,23 +316,30 @@ def main():
         merge_desc = {"reduce": "min reduce to rank 0", "allreduce": "min all-reduce",
                       "a2a": "all-to-all of frame slices + local min/resolve + all-gather of the image"}[args.merge]
     if rank == 0:
+        layout_desc = {"point_windows": "stream resident as per-point 64-bit windows (8 B/point), decode variant point_windows",
+                       "words": "stream resident as lane-major packed words (~3 B/point read), decode variant words"}[args.layout]
         out = {
             "metric": "Mpoints/s decoded+rasterized @%dx%d" % (args.width, args.height),
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if fixed_total else "weak", "vs_baseline": None,
             "dtype": "u64 keys / i32 deltas / f32 projection", "data": "synthetic",
-            "config": {"workload": "%d synthetic Morton-sorted points per GPU, per-batch 12-bit-clipped Huffman, %dx%d, %s, camera %s, LOD%%=%d, cull=%d"
-                                   % (args.points, args.width, args.height,
-                                      "basic atomicMin raster" if args.method == "basic" else "HQS two-pass", args.camera, args.lod, args.cull),
+            "config": {"workload": "%d synthetic Morton-sorted points %s, per-batch 12-bit-clipped Huffman, %dx%d, %s, camera %s, LOD%%=%d, cull=%d; %s"
+                                   % (total_points if fixed_total else args.points, "in total over the node" if fixed_total else "per GPU",
+                                      args.width, args.height,
+                                      "basic atomicMin raster" if args.method == "basic" else "HQS two-pass", args.camera, args.lod, args.cull, layout_desc),
                        "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
                        "parallelism": ("batch-sharded x%d + RCCL %s%s" % (world, merge_desc, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
-                       "generate_s": round(t_gen, 2), "load_s": round(t_load, 2),
+                       "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "preroll_s": args.preroll,
                        "first_frame_ms": round(first_frame_ms, 3)},
+            "step_ms": {"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4), "max": round(max(step_ms), 4),
+                        "n": len(step_ms), "how": "single steps after the timed region, one HIP event pair and one sync each"} if step_ms else None,
             "roofline": roofline,
+            "variants": variants,
             "cpu_baseline": cpu_baseline,
             "parity_full_size": parity,
+            "depth_ties": ties,
         }
         print(json.dumps(out), flush=True)
 

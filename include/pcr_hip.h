@@ -181,6 +181,8 @@ int pcr_set_render_variant(pcr_ctx *ctx, int variant);
 /* Device bytes the loaded stream occupies right now (every per-stream allocation of the context, pads and guards included;
  * framebuffers excluded). Drops when the first frame after the last upload releases what only the load-time transcode reads. */
 int64_t pcr_stream_resident_bytes(const pcr_ctx *ctx);
+/* Version tag of the render/transcode kernels in this library ("rNN.vMM"): stored measurements name the tag they belong to. */
+const char *pcr_kernel_version(void);
 
 /* pcr_clear and the cull/LOD prepass of the frame's first render call in ONE launch: equivalent to pcr_clear followed by
  * what pcr_render_basic (method PCR_METHOD_BASIC) or pcr_render_hqs_depth (PCR_METHOD_HQS) would do first. The render call

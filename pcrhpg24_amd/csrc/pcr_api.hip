@@ -58,7 +58,7 @@ struct pcr_ctx {
     bool any_generic_pending = false;
     uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
     uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
-    uint2 *d_point_windows = nullptr;           // PCR_LAYOUT_POINT_WINDOWS: 64-bit view per point (k_transcode), PW_ROWS x 1024 per batch
+    uint8_t *d_point_windows = nullptr;         // PCR_LAYOUT_POINT_WINDOWS: 48-bit view per point (k_transcode), PW_BATCH_BYTES per batch
     int layout = PCR_LAYOUT_POINT_WINDOWS;      // of the stream being loaded (pcr_set_stream_layout, fixed at pcr_stream_begin)
     int next_layout = PCR_LAYOUT_POINT_WINDOWS;
     int variant = PCR_VARIANT_AUTO;             // which k_render variant draws a stream that has both layouts resident
@@ -349,6 +349,10 @@ extern "C" {
 
 const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+// Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
+// from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
+const char *pcr_kernel_version(void) { return "r02.v38"; }
+
 int pcr_create(int device, pcr_ctx **out)
 {
     if (!out) return set_err(nullptr, PCR_E_ARG, "out is NULL");
@@ -460,7 +464,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
         (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES, acc)) ||
         (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
-        (windows && (rc = dalloc_zero(c, c->d_point_windows, (nB * PW_ROWS + PW_GUARD_ROWS) * PCR_WORKGROUP_SIZE, acc)))) {
+        (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc)))) {
         free_stream_buffers(c);
         return rc;
     }

@@ -63,15 +63,18 @@ __device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_byt
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
 constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
-// Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 64 bits of the chain's own
+// Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 48 bits of the chain's own
 // bit stream that start at the point's first bit -- its three symbols (<= 36 bits) and the look-ahead of the next point's
-// first symbol (12 more) lie inside. Row i holds the windows of the batch's 1024 chains: every lane of k_render reads row
-// i at point i (8 bytes per lane, 512 contiguous bytes per wave), with no word queue to maintain. 8 bytes per point of
-// HBM instead of the ~3 the packed words take: bytes traded for instructions on a kernel that is issue bound with 5x
-// of HBM bandwidth to spare. PW_GUARD_ROWS: k_render requests two rows ahead.
+// first symbol (12 more) lie inside. Stored as two planes per batch: PW_ROWS rows of 1024 x u32 (bits 0..31 of the window)
+// followed by PW_ROWS rows of 1024 x u16 (bits 32..47). Row i is read at point i by every lane of k_render (256 + 128
+// contiguous bytes per wave), with no word queue to maintain: 6 bytes per point of HBM instead of the ~3 the packed words
+// take -- bytes traded for instructions. (Round 1 stored 64 bits per point; the last 16 were never looked at.)
+// PW_GUARD_BYTES: k_render requests two rows ahead, the last batch's low plane is followed by this much slack.
 constexpr int PW_ROWS        = PCR_POINTS_PER_THREAD;
-constexpr uint32_t PW_ROW_BYTES = PCR_WORKGROUP_SIZE * 8;
-constexpr int PW_GUARD_ROWS  = 2;
+constexpr uint32_t PW_HI_ROW_BYTES = PCR_WORKGROUP_SIZE * 4, PW_LO_ROW_BYTES = PCR_WORKGROUP_SIZE * 2;
+constexpr uint32_t PW_HI_BYTES = PW_ROWS * PW_HI_ROW_BYTES;                 // offset of the low plane inside a batch's block
+constexpr uint32_t PW_BATCH_BYTES = PW_ROWS * (PW_HI_ROW_BYTES + PW_LO_ROW_BYTES);   // 384 KiB
+constexpr uint32_t PW_GUARD_BYTES = 2 * PW_LO_ROW_BYTES;
 enum { LAYOUT_WORDS = 0, LAYOUT_POINT_WINDOWS = 1 };
 // batch_flags: set when some chain of the batch can meet an in-table value outside the packed entry's range or read an
 // escape word outside k_render's LDS pool (k_transcode walks all 192 symbols of every chain, garbage tails included)
@@ -101,7 +104,7 @@ struct StreamView {
     const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
-    const uint2    *point_windows;    // [(nB*PW_ROWS + PW_GUARD_ROWS)*1024] or NULL (layout), written by k_transcode
+    const uint8_t  *point_windows;    // [nB * PW_BATCH_BYTES + PW_GUARD_BYTES] or NULL (layout), written by k_transcode
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
@@ -395,7 +398,7 @@ __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lby
 // without checking (batch_flags).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
-                                                                  uint32_t *packed_table, uint2 *point_windows,
+                                                                  uint32_t *packed_table, uint8_t *point_windows,
                                                                   uint32_t *any_generic, int first_batch, int lane_words_first)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
@@ -440,13 +443,15 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     uint32_t ep = 64, next_cross = 2 * CHUNK_WORDS;         // already_read (:418)
     uint32_t sft = 32 + 20;                                 // cur_bits (:419) + 20: (bits >> sft) & 0xFFF is the key of :431-433
     uint32_t nesc = 0;
-    uint2 *pw = point_windows ? point_windows + (size_t)b * PW_ROWS * PCR_WORKGROUP_SIZE + tid : nullptr;
+    // my column of the batch's two window planes (high: u32 per point, low: u16 per point)
+    uint32_t *pw = point_windows ? reinterpret_cast<uint32_t *>(point_windows + (size_t)b * PW_BATCH_BYTES) + tid : nullptr;
+    uint16_t *pwl = point_windows ? reinterpret_cast<uint16_t *>(point_windows + (size_t)b * PW_BATCH_BYTES + PW_HI_BYTES) + tid : nullptr;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < PCR_POINTS_PER_THREAD * 3; ++k) {   // :428-430
         // first bit of point k/3 in the chain's own word sequence: `bits` holds rows row-2 and row-1, of which 52 - sft
         // bits are consumed (parked in the window slot until the words behind it are known, see below)
-        if (pw && k % 3 == 0) pw[(size_t)(k / 3) * PCR_WORKGROUP_SIZE].x = 32u * (row - 2u) + (52u - sft);
+        if (pw && k % 3 == 0) pw[(size_t)(k / 3) * PCR_WORKGROUP_SIZE] = 32u * (row - 2u) + (52u - sft);
         const uint32_t l = s_len[(uint32_t)(bits >> sft) & 0xFFFu];
         sft -= l & 0x7Fu;                                   // :435-439
         nesc += l >> 7;                                     // :438
@@ -492,14 +497,15 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         __threadfence();            // my own stores above (lane_words column, parked positions) before I read them back
 #pragma unroll 4
         for (int i = 0; i < PW_ROWS; ++i) {
-            const uint32_t pos = pw[(size_t)i * PCR_WORKGROUP_SIZE].x;
+            const uint32_t pos = pw[(size_t)i * PCR_WORKGROUP_SIZE];
             const uint32_t r = pos >> 5, o = pos & 31u;
             const uint32_t a0 = out[(size_t)r * PCR_WORKGROUP_SIZE], a1 = out[(size_t)(r + 1) * PCR_WORKGROUP_SIZE],
                            a2 = out[(size_t)(r + 2) * PCR_WORKGROUP_SIZE];
             // alignbit(hi, lo, s) = low 32 bits of (hi:lo) >> (s & 31): s = 32 - o cuts 32 bits starting o bits into hi
             const uint32_t hi = o ? __builtin_amdgcn_alignbit(a0, a1, 32u - o) : a0;
             const uint32_t lo = o ? __builtin_amdgcn_alignbit(a1, a2, 32u - o) : a1;
-            pw[(size_t)i * PCR_WORKGROUP_SIZE] = make_uint2(lo, hi);     // little-endian u64: x = low half
+            pw[(size_t)i * PCR_WORKGROUP_SIZE] = hi;                     // bits 0..31 of the window
+            pwl[(size_t)i * PCR_WORKGROUP_SIZE] = (uint16_t)(lo >> 16);  // bits 32..47
         }
     }
 }
@@ -642,21 +648,24 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // point i (requested two points earlier) and there is no queue.
     const char *lwb = reinterpret_cast<const char *>(a.s.lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE);   // uniform
     auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + byte_off); };
-    const char *pwb = reinterpret_cast<const char *>(a.s.point_windows + (size_t)b * PW_ROWS * PCR_WORKGROUP_SIZE); // uniform
-    auto pw_load = [&](uint32_t byte_off) -> uint64_t { return *reinterpret_cast<const uint64_t *>(pwb + byte_off); };
-    uint32_t lwo = tid * 4;                                 // byte offset of my column in the row of far0
+    const char *pwb = reinterpret_cast<const char *>(a.s.point_windows) + (size_t)b * PW_BATCH_BYTES;               // uniform
+    // the 48-bit window of a point as the top of a 64-bit view: high plane u32, low plane u16 (the 16 bits below are zero)
+    auto pw_load_hi = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pwb + byte_off); };
+    auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint16_t *>(pwb + byte_off); };
+    uint32_t lwo = tid * 4;                                 // byte offset of my column in the row of far0 / in the high plane's row
+    uint32_t lwo2 = PW_HI_BYTES + tid * 2;                  // ... in the low plane's row
     uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
-    uint64_t bits, nwin = 0;
+    uint64_t bits;
+    uint32_t nwin_hi = 0, nwin_lo = 0;
     if (LAYOUT == LAYOUT_WORDS) {
         w1 = lw_load(lwo); w2 = lw_load(lwo + LW_ROW_BYTES);
         far0 = lw_load(lwo + 2 * LW_ROW_BYTES); far1 = lw_load(lwo + 3 * LW_ROW_BYTES);
         lwo += 2 * LW_ROW_BYTES;
         bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
     } else {
-        lwo = tid * 8;                                      // byte offset of my column in the row of nwin
-        bits = pw_load(lwo);
-        lwo += PW_ROW_BYTES;
-        nwin = pw_load(lwo);
+        bits = ((uint64_t)pw_load_hi(lwo) << 32) | (pw_load_lo(lwo2) << 16);
+        lwo += PW_HI_ROW_BYTES; lwo2 += PW_LO_ROW_BYTES;
+        nwin_hi = pw_load_hi(lwo); nwin_lo = pw_load_lo(lwo2);
     }
     constexpr uint32_t SFT0 = 50;                           // (bits >> 50) & 0x3FFC = 4 x the top 12 bits of the view
     uint32_t sft = SFT0;
@@ -742,7 +751,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #define PCR_ADVANCE_WORD_WINDOW()                                                          \
     do {                                                                                   \
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {                                              \
-            bits = nwin;                                                                   \
+            bits = ((uint64_t)nwin_hi << 32) | (nwin_lo << 16);                            \
             sft = SFT0;                                                                    \
             break;                                                                         \
         }                                                                                  \
@@ -912,12 +921,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
       const int seg_end = min(seg + 16, npr_run);
 #pragma unroll 1
       for (int i = seg; i < seg_end; ++i) {                                 // :428
-        uint64_t fetched = 0;
+        uint32_t fetched_hi = 0, fetched_lo = 0;
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {
             // row i+2, requested at the top of point i and taken over at its very end: a whole point of latency cover
-            // (past row 63 lie the next batch's rows or the guard)
-            lwo += PW_ROW_BYTES;
-            fetched = pw_load(lwo);
+            // (past row 63 of a plane lies the batch's other plane, the next batch, or the guard)
+            lwo += PW_HI_ROW_BYTES; lwo2 += PW_LO_ROW_BYTES;
+            fetched_hi = pw_load_hi(lwo); fetched_lo = pw_load_lo(lwo2);
         }
 #ifdef PCR_EXP_EXTRA_LOAD   /* experiment: 4 (or 8) more bytes of HBM traffic per point, consumed at the end of the point */
         const uint32_t extra0 = lw_load((uint32_t)i * LW_ROW_BYTES + tid * 4);
@@ -937,7 +946,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         PCR_ADVANCE_WORD_WINDOW();
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) g_fb[tid] = 0;
-        if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo; }
         continue;
 #endif
         if (use_double) {                                                   // :459-461
@@ -957,7 +966,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #else
         project_request();
 #endif
-        if (LAYOUT == LAYOUT_POINT_WINDOWS) nwin = fetched;
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo; }
 #ifdef PCR_EXP_EXTRA_LOAD
         asm volatile("; extra load consumed %0" :: "v"(extra0));
 #if PCR_EXP_EXTRA_LOAD > 1

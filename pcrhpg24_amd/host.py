@@ -82,6 +82,11 @@ def synth_encode(total_points: int, seed: int = 0x5EED, first: int = 0, count: O
     return NativeBytes(out.value, ln.value), st.as_dict()
 
 
+def kernel_version() -> str:
+    """Version tag of the render/transcode kernels in libpcr_hip.so (pcr_kernel_version): stored measurements name theirs."""
+    return N.hip_lib().pcr_kernel_version().decode()
+
+
 def synth_points(total_points: int, seed: int, first: int, count: int):
     x = np.empty(count, np.int32); y = np.empty(count, np.int32); z = np.empty(count, np.int32)
     c = np.empty(count, np.uint32)
