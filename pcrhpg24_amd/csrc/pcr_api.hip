@@ -92,6 +92,8 @@ struct pcr_ctx {
     bool prepass_ready = false;
     pcr_render_params prepass_params{};
     int prepass_variant_hqs = 0, prepass_win_pixel_bytes = 0;
+    uint32_t prepass_dyn_lds = 0;
+    bool big_lds_ready = false;                 // hipFuncSetAttribute done for the 140 KiB launches
     int64_t prepass_batches = 0;
     static constexpr int FENCES = 8;
     hipEvent_t fence[FENCES] = {};              // pcr_fence_record / pcr_fence_wait: device-scope ordering between streams
@@ -275,6 +277,33 @@ void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
     }
 }
 
+// Dynamic LDS of a frame's k_render launches: the small configuration (two workgroups per CU) unless the image has more
+// pixels than the loaded batches' small windows hold together -- then most points would leave the windows and the frame is
+// bound by global pre-reads and atomics; one workgroup per CU with windows of ~17 000 pixels keeps them in LDS.
+uint32_t frame_dyn_lds(const pcr_ctx *c, int64_t nB)
+{
+    return (int64_t)c->width * c->height > nB * (int64_t)WIN_PIXELS ? (uint32_t)DYN_LDS_BYTES_BIG : (uint32_t)DYN_LDS_BYTES;
+}
+
+template <int MODE, int LAYOUT, bool GENERIC> hipError_t allow_big_lds()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<MODE, LAYOUT, GENERIC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS_BYTES_BIG);
+}
+int enable_big_lds(pcr_ctx *c)
+{
+    if (c->big_lds_ready) return PCR_OK;
+    hipError_t e = hipSuccess;
+#define PCR_ALLOW(M, L) if (e == hipSuccess) e = allow_big_lds<M, L, false>(); if (e == hipSuccess) e = allow_big_lds<M, L, true>()
+    PCR_ALLOW(MODE_BASIC, LAYOUT_WORDS); PCR_ALLOW(MODE_BASIC, LAYOUT_POINT_WINDOWS);
+    PCR_ALLOW(MODE_HQS_DEPTH, LAYOUT_WORDS); PCR_ALLOW(MODE_HQS_DEPTH, LAYOUT_POINT_WINDOWS);
+    PCR_ALLOW(MODE_HQS_COLOR, LAYOUT_WORDS); PCR_ALLOW(MODE_HQS_COLOR, LAYOUT_POINT_WINDOWS);
+#undef PCR_ALLOW
+    if (e != hipSuccess) return set_err(c, PCR_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+    c->big_lds_ready = true;
+    return PCR_OK;
+}
+
 // Once the whole stream is loaded and every batch has its final transcode, what only k_transcode reads is dead weight:
 // the raw cluster-interleaved words (the largest array of the file), the int32 / int8 decoder tables (k_render reads the
 // packed entries; the int32 values stay if some batch has `wide` entries), the cluster prefix and the transcode scratch.
@@ -305,11 +334,15 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     maybe_finalize(c);
     const int win_pixel_bytes = MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
     const int variant_hqs = MODE != MODE_BASIC;
+    const uint32_t dyn_lds = frame_dyn_lds(c, nB);
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
-                              c->prepass_win_pixel_bytes == win_pixel_bytes && std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
+                              c->prepass_win_pixel_bytes == win_pixel_bytes && c->prepass_dyn_lds == dyn_lds &&
+                              std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
     c->prepass_ready = false;
     RenderArgs a = make_args(c, p, variant_hqs);
     a.win_pixel_bytes = win_pixel_bytes;
+    a.dyn_lds_bytes = dyn_lds;
+    if (dyn_lds > (uint32_t)DYN_LDS_BYTES && (rc = enable_big_lds(c))) return rc;
     if (!have_prepass) {
         c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
         hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
@@ -331,11 +364,11 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     // kernel (second list) is launched only if the stream may hold a flagged batch.
     const bool generic = maybe_generic_batches(c);
     if (windows) {
-        hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
-        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+        hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
+        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
     } else {
-        hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
-        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), 0, c->stream, a);
+        hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
+        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
     }
     if (timed) { HIP_TRY(c, hipEventRecord(c->kt_end[slot], c->stream)); ++c->kt_samples; }
     if (c->kt_every > 0) ++c->kt_launches;
@@ -351,7 +384,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r02.v38"; }
+const char *pcr_kernel_version(void) { return "r02.v41"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -775,6 +808,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     maybe_finalize(c);
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
+    a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
                        (uint32_t)c->stats_partials, c->fb, rg, ba, c->fb_elems, c->empty_key);
@@ -782,6 +816,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     c->accum_dirty = false;
     c->prepass_ready = true;
     c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_pixel_bytes = a.win_pixel_bytes;
+    c->prepass_dyn_lds = a.dyn_lds_bytes;
     c->prepass_batches = nB;
     return PCR_OK;
 }

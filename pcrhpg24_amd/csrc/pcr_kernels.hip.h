@@ -35,14 +35,19 @@ constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                 
 // pool takes what the batch's escapes need (up to ESC_POOL_WORDS, which leaves 1024 window pixels), the window gets the rest.
 // The benchmark stream's batches have 3831..7037 escape words: windows of 4090..5760 pixels. A fixed 24 + 36 KiB split put 6 %
 // of those batches on the checked escape path, 1.5x slower each, and they finished last on their CUs (+17 % per launch).
+// DYN_LDS_BYTES_BIG: the same kernels launched with 140 KiB of it -- one workgroup per CU, windows of up to ~17 000 pixels --
+// for frames whose batches' rectangles outgrow the small windows (4096x4096 over 1526 batches: most points would go through
+// global pre-reads and global atomics; with the big windows k_render 0.564 -> 0.48 ms). At 1080p it is 40 % slower: half
+// the waves per SIMD. The host chooses per frame (launch_render); the size travels in RenderArgs::dyn_lds_bytes.
 constexpr int DYN_LDS_BYTES  = 60 * 1024;
+constexpr int DYN_LDS_BYTES_BIG = 140 * 1024;
 constexpr int ESC_POOL_WORDS = 13312;            // most escape words of a batch the pool ever holds -> 52 KiB
 constexpr int ESC_POOL_EAGER = 7168;             // words every workgroup requests before it knows the batch's count
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
 constexpr int WIN_PIXELS     = 4096;             // nominal window (a batch with 7104 escape words); the 10-10-10 kernel's fixed one
 constexpr int WIN_PIXEL_BYTES     = 8;           // basic / HQS depth: the u64 framebuffer word
 constexpr int WIN_PIXEL_BYTES_HQS = 20;          // HQS colour: {RG u64, BA u64, depth u32}
-constexpr int WIN_PIXELS_MAX = DYN_LDS_BYTES / WIN_PIXEL_BYTES;
+constexpr int WIN_PIXELS_MAX = DYN_LDS_BYTES / WIN_PIXEL_BYTES;         // of the small configuration
 // How many of a batch's escape words k_render keeps in LDS: all of them plus ESC_SLACK words that follow them in memory
 // (the reference's tail over-reads), or as many as the pool holds. A batch with more than that is flagged
 // (BF_GENERIC_SLOW_PATH) and its chains check every escape index: the first ESC_POOL_WORDS still come from LDS, only
@@ -54,9 +59,9 @@ __device__ __forceinline__ uint32_t esc_pool_words(uint32_t esc_total)
 }
 __device__ __forceinline__ uint32_t esc_pool_bytes(uint32_t pool_words) { return (pool_words * 4u + 15u) & ~15u; }
 // pixels the batch's LDS window can hold next to its escape pool
-__device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_bytes)
+__device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_bytes, uint32_t dyn_lds_bytes)
 {
-    return (int)((DYN_LDS_BYTES - esc_pool_bytes(esc_pool_words(esc_total))) / (uint32_t)pixel_bytes);
+    return (int)((dyn_lds_bytes - esc_pool_bytes(esc_pool_words(esc_total))) / (uint32_t)pixel_bytes);
 }
 
 // Lane-major copy of the word stream (k_transcode): row r holds the r-th word each of the batch's 1024 chains consumes.
@@ -138,6 +143,7 @@ struct RenderArgs {
     uint32_t order_stride;    // prepass workgroups * PREPASS_BATCHES
     int variant_hqs;          // LOD expression variant
     int win_pixel_bytes;      // what a window pixel of the following k_render<MODE> takes in LDS (WIN_PIXEL_BYTES*)
+    uint32_t dyn_lds_bytes;   // dynamic LDS of the following k_render launch: DYN_LDS_BYTES or DYN_LDS_BYTES_BIG
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -283,7 +289,7 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
     // Screen rectangle of the batch's bounding box: where k_render keeps its LDS copy of the framebuffer. This is
     // only a cache placement hint (points that land outside it take the global path), so it needs no exactness.
     uint2 wr = make_uint2(0, 0);
-    const int win_capacity = window_capacity((uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023], a.win_pixel_bytes);
+    const int win_capacity = window_capacity((uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023], a.win_pixel_bytes, a.dyn_lds_bytes);
     {
         // corner `lane` of the box, then min / max over the group's eight lanes
         const int c = lane;
@@ -562,7 +568,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const float m10 = a.p.transform[4], m11 = a.p.transform[5], m12 = a.p.transform[6], m13 = a.p.transform[7];
 
     __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
-    __shared__ __align__(16) unsigned char s_dyn[DYN_LDS_BYTES];            // escape pool, then the framebuffer window
+    extern __shared__ __align__(16) unsigned char s_dyn[];                  // a.dyn_lds_bytes: escape pool, then the framebuffer window
     int32_t *const s_esc = reinterpret_cast<int32_t *>(s_dyn);
 
     // decoder table -> LDS (render.cu:383-395), four entries per thread, already packed by k_transcode
@@ -586,7 +592,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // batches that do not fit, go to global memory (slow variant of the decode step).
     const uint32_t esc_lds = esc_pool_words(esc_total);
     unsigned long long *const s_win = reinterpret_cast<unsigned long long *>(s_dyn + esc_pool_bytes(esc_lds));
-    const uint32_t win_cap = (uint32_t)window_capacity(esc_total, MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES);
+    const uint32_t win_cap = (uint32_t)window_capacity(esc_total, MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES, a.dyn_lds_bytes);
     {   // all loads of a thread in flight together, requested before the batch's escape count is known (7 per thread)
         int32_t v[ESC_POOL_EAGER / PCR_WORKGROUP_SIZE];
 #pragma unroll
@@ -606,7 +612,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             if (i < esc_lds) s_esc[i] = v[k];
         }
     }
-    uint32_t sp4 = tid ? 4u * (uint32_t)ssz[tid - 1] : 0u;  // :411-413 (batch-relative), as a byte offset into the pool
+    // :411-413 (batch-relative): my chain's next escape word, as a pointer into the pool (the LDS address travels in one
+    // register: nothing to add per read)
+    const int32_t *esc_next = s_esc + (tid ? (uint32_t)ssz[tid - 1] : 0u);
 
     // ---- framebuffer window of the batch's rectangle -> LDS --------------------------------------------------
     const uint2 wr = a.win[b];
@@ -617,20 +625,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // colour pass layout of the same bytes: sums in the framebuffer's own packed format + the depth to test against
     unsigned long long *const s_rg = s_win, *const s_ba = s_win + win_cap;
     uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * win_cap);
-    {   // snapshot of the rectangle, all loads of a thread in flight together (a stale value is a valid start)
+    // snapshot of the rectangle, K_WIN loads of a thread in flight together (a stale value is a valid start); one round
+    // covers the small configuration's largest window
+    for (uint32_t i0 = 0; i0 < wpix; i0 += WIN_PIXELS_MAX) {                // (uniform)
         constexpr int K_WIN = (WIN_PIXELS_MAX + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE;
         unsigned long long v[K_WIN];
 #pragma unroll
         for (int k = 0; k < K_WIN; ++k) {
-            const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
+            const uint32_t i = i0 + tid + k * PCR_WORKGROUP_SIZE;
             uint32_t y, x;
             window_row_col(i, ww, inv_ww, y, x);
             v[k] = i < wpix ? a.f.fb[(size_t)(wy0 + y) * W + wx0 + x] : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < K_WIN; ++k) {
-            const uint32_t i = tid + k * PCR_WORKGROUP_SIZE;
-            if (i < wpix) {
+            const uint32_t i = i0 + tid + k * PCR_WORKGROUP_SIZE;
+            if (i < wpix && tid + k * PCR_WORKGROUP_SIZE < WIN_PIXELS_MAX) {
                 if (MODE == MODE_HQS_COLOR) { s_depth[i] = (uint32_t)(v[k] >> 32); s_rg[i] = 0; s_ba[i] = 0; }
                 else                        s_win[i] = v[k];
             }
@@ -713,9 +723,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     };
     // `valid`: the pending point is inside the frustum; `off`: ... but outside the batch's LDS window (then `pix` is its pixel
     // and `old` came from global memory). Both are lane masks the compiler keeps in scalar registers, so choosing between the
-    // LDS and the global path costs no vector instruction. `w`: the window word of the pixel, as a byte offset into s_win
-    // (basic / depth pass) or as an index (colour pass: three planes).
-    auto scatter = [&](bool valid, bool off, uint32_t pix, uint32_t w, uint32_t depth, uint64_t old, int point) __attribute__((always_inline)) {
+    // LDS and the global path costs no vector instruction. The window word of the pixel: `wp` (basic / depth pass) or the
+    // index `w` (colour pass: three planes).
+    auto scatter = [&](bool valid, bool off, uint32_t pix, uint32_t w, unsigned long long *wp, uint32_t depth, uint64_t old, int point) __attribute__((always_inline)) {
         if (MODE == MODE_HQS_COLOR) {
             const float pw = __uint_as_float(depth);
             const float old_depth = __uint_as_float((uint32_t)(old >> 32));
@@ -742,7 +752,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         if (!((((unsigned long long)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload)) < old)) return;
 #endif
         const unsigned long long key = ((unsigned long long)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload);   // :299 / depth.cu:139-145
-        if (!off) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_win) + w), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!off) __hip_atomic_fetch_min(wp, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else      atomicMin((unsigned long long *)&g_fb[pix], key);         // :300
     };
 
@@ -773,6 +783,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     bool pend_valid = false, pend_off = false;
     uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
+    unsigned long long *pend_p = s_win;                     // basic / depth pass: the pending point's word in the LDS window
     uint64_t pend_old = 0;
 
     const float *M = a.p.transform;
@@ -823,17 +834,16 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         int32_t val = (int32_t)e >> TE_VALUE_SHIFT;                         // the delta itself (v_ashrrev_i32)
         if (val == TE_SLOW_VALUE) {                                         // escape or wide
             if (!GENERIC) {                                                 // every such entry is an escape whose word is in the pool
-                val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
-                sp4 += 4;
+                val = *esc_next++;
             } else if (e & TE_ESCAPE) {                                     // :438
-                if (sp4 < 4u * esc_lds) {
-                    val = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(s_esc) + sp4);
+                if (esc_next < s_esc + esc_lds) {
+                    val = *esc_next;
                 } else {
                     // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
-                    val = sep_load(sp4 >> 2);
+                    val = sep_load((uint32_t)(esc_next - s_esc));
                     asm volatile("; escape word from global memory %0" : "+v"(val));
                 }
-                sp4 += 4;
+                ++esc_next;
             } else {
                 val = tvalues[toff >> 2];
                 asm volatile("; wide table value from global memory %0" : "+v"(val));
@@ -895,14 +905,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
             in_window = rx < ww && ry < wh;
             off_window = !in_window;
-            pend_w = MODE == MODE_HQS_COLOR ? ry * ww + rx : (ry * ww + rx) * 8u;
+            if (MODE == MODE_HQS_COLOR) pend_w = ry * ww + rx; else pend_p = s_win + (ry * ww + rx);
         }
         pend_valid = inside;
         pend_off = off_window;
         // (two separate steps, the LDS read first: a load into the same registers issued behind it only has to wait for
         // the LDS counter, the other way round the LDS read would wait for every vector-memory load in flight)
-        if (in_window) pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32
-                                                         : *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(s_win) + pend_w);
+        if (in_window) pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
         if (off_window) {
             pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
             pend_old = g_fb[pend_pix];
@@ -912,7 +921,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     for (int seg = 0; seg < npr_run; seg += 16) {
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
-      scatter(pend_valid, pend_off, pend_pix, pend_w, pend_depth, pend_old, seg - 1);
+      scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, seg - 1);
       pend_valid = false;
       if (MODE != MODE_HQS_DEPTH) {
           pal = bc1_palette(cnext);                     // once per 16 points instead of once per surviving point
@@ -937,9 +946,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const uint32_t d0 = symbol_step();                                  // :430
         // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
         // word has been in flight since the end of the last iteration
-        scatter(pend_valid, pend_off, pend_pix, pend_w, pend_depth, pend_old, i - 1);
+        // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
+        if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
         const uint32_t d1 = symbol_step();
         const uint32_t d2 = symbol_step();
+        if (MODE == MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
         pz = (int32_t)((uint32_t)pz + d2);
@@ -975,7 +986,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
       }
     }
-    scatter(pend_valid, pend_off, pend_pix, pend_w, pend_depth, pend_old, npr_run - 1);
+    scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, npr_run - 1);
     if (MODE == MODE_HQS_COLOR) flush_run();
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave

@@ -125,3 +125,29 @@ def test_gpu_encoder_reproduces_the_stream(big, whole):
     x, y, z, c = P.synth_points(N, scenes.SEED, 0, N)
     gpu, st = whole.gpu_encode_points(x, y, z, c, P.synth_las_info(N, scenes.SEED), morton_sort=True)
     assert hashlib.sha256(gpu.view()).digest() == hashlib.sha256(image.view()).digest()
+
+
+def test_4096x4096_with_culling_matches_the_oracle(big):
+    """BASELINE configs[4], the one-GPU half: 1e8 points at 4096x4096 with the per-batch frustum cull on. The batches'
+    screen rectangles outgrow the small LDS windows here, so the library launches k_render with its 140 KiB windows
+    (one workgroup per CU); an orbit camera that culls about half of the batches makes the compacted batch list short."""
+    _, hf, of = big
+    c = P.Context(0)
+    try:
+        c.set_image_size(4096, 4096)
+        c.stream_begin(hf.header(), 0)
+        for b0 in range(0, hf.numBatches, 100):
+            c.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
+        for name, cam, lod in (("overview", P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), 4096, 4096), 100),
+                               ("half culled", P.camera_orbit(0.6, -0.5, 420.0, (250.0, 250.0, 40.0), 4096, 4096), 10)):
+            p = scenes.with_flags(cam, lod_percent=lod, cull=1)
+            c.frame_begin(p); c.render_basic(p); c.resolve_basic(p)
+            fb = c.read_framebuffer(full=True)
+            ofb, ost = of.render_basic(p, nthreads=16)
+            assert c.stats() == ost, name
+            assert np.array_equal(fb, ofb), name
+            assert np.array_equal(c.read_rgba(), oracle.resolve_basic(p, ofb)), name
+            if name == "half culled":
+                assert 0.25 * hf.numBatches < ost["batches_culled"] < 0.75 * hf.numBatches, ost
+    finally:
+        c.close()
