@@ -1,0 +1,72 @@
+/*
+ * pcr_dist.h — C ABI of the multi-GPU layer: libpcr_dist.so (C++ over RCCL, links libpcr_hip.so).
+ *
+ * The reference is single-GPU (src/main.cpp:61 creates one context on device 0; no NCCL/MPI call site anywhere: SURVEY
+ * 2.3), so nothing here replaces a reference interface; it is the "batches statically sharded over the GPUs of a node,
+ * per-pixel min merge of the partial framebuffers over RCCL/xGMI" of BASELINE.json's north_star, built the way the
+ * reference's host code is built: C++ calling the device library through a C ABI.
+ *
+ * Model: one pcr_ctx per GPU holds a contiguous range of the stream's batches (pcr_dist_shard_range) and a full-size
+ * private framebuffer. A frame is: every rank renders its shard, then ONE exchange step merges the partial frames --
+ *     basic :  ncclReduce / ncclAllReduce(fb, ncclUint64, ncclMin)      min is associative and commutative on the packed
+ *                                                                       {depth, colour} words: bit-identical to one GPU
+ *     HQS   :  depth pass -> ncclAllReduce(fb, ncclUint64, ncclMin)     every rank tests against the GLOBAL depth
+ *              colour pass -> ncclReduce(RG | BA, ncclUint64, ncclSum)  packed 2 x 32-bit sums, no carry between halves
+ * in place, on the context's own stream (stream order against the render kernels, no host synchronisation).
+ * RCCL's native unsigned 64-bit min is used, so the framebuffer keeps its all-ones "empty" word (the torch transport of
+ * pcrhpg24_amd/dist.py needs pcr_set_int64_mergeable because torch exposes signed int64 only).
+ *
+ * Two ways to form the communicator:
+ *   one process per GPU   rank 0 calls pcr_dist_unique_id, the launcher carries the 128 bytes to every rank (environment,
+ *                         file, MPI, torch.distributed: the library does not care), every rank calls pcr_dist_create;
+ *   one process, N GPUs   pcr_dist_create_local over N contexts on N different devices; collectives of the N ranks are
+ *                         then issued between pcr_dist_group_begin / pcr_dist_group_end (pcr_render_dist does this).
+ * All functions return PCR_OK or a negative PCR_E_* code; the message is available from pcr_dist_last_error().
+ */
+#ifndef PCR_DIST_H
+#define PCR_DIST_H
+
+#include "pcr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcr_dist pcr_dist;       /* one rank: a communicator bound to one pcr_ctx */
+
+#define PCR_DIST_ID_BYTES 128           /* sizeof(ncclUniqueId) */
+#define PCR_DIST_ALL (-1)               /* root value: every rank receives the merged frame (all-reduce) */
+
+const char *pcr_dist_last_error(void);  /* thread-local */
+
+/* Contiguous [first, first + count) of `units` (batches, or loader chunks) for `rank` of `world`; sizes differ by at most
+ * one, earlier ranks take the larger shares. Pure arithmetic (the same split as pcrhpg24_amd/dist.py::shard_range). */
+void pcr_dist_shard_range(int64_t units, int world, int rank, int64_t *first, int64_t *count);
+
+int pcr_dist_unique_id(unsigned char id[PCR_DIST_ID_BYTES]);
+int pcr_dist_create(pcr_ctx *ctx, const unsigned char id[PCR_DIST_ID_BYTES], int rank, int world, pcr_dist **out);
+/* n contexts of this process, each on a different device, become ranks 0..n-1 of one communicator; out[n]. */
+int pcr_dist_create_local(pcr_ctx *const *ctxs, int n, pcr_dist **out);
+void pcr_dist_destroy(pcr_dist *d);
+int pcr_dist_rank(const pcr_dist *d);
+int pcr_dist_world(const pcr_dist *d);
+
+/* Bracket the collectives of several ranks issued by one thread (ncclGroupStart / ncclGroupEnd). */
+int pcr_dist_group_begin(void);
+int pcr_dist_group_end(void);
+
+/* The exchange step, in place on the context's current framebuffers and stream. root = rank that receives the result, or
+ * PCR_DIST_ALL. After a reduce the other ranks' buffers are unspecified (they are cleared by the next frame anyway). */
+int pcr_dist_merge_min(pcr_dist *d, int root);          /* fb: u64 min */
+int pcr_dist_merge_sum(pcr_dist *d, int root);          /* RG and BA: u64 sum */
+
+/* Whole frames: clear + shard render + merge (+ resolve on the ranks that hold the result). With one thread driving
+ * several ranks, call the *_begin halves for every rank, then the *_merge halves between group_begin/group_end, then the
+ * *_finish halves; pcr_dist_frame_basic / _hqs do all three for the one-process-per-GPU case. */
+int pcr_dist_frame_basic(pcr_dist *d, const pcr_render_params *p, int root);
+int pcr_dist_frame_hqs(pcr_dist *d, const pcr_render_params *p, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -127,6 +127,11 @@ int pcr_read_rgba(pcr_ctx *ctx, uint32_t *host, size_t n_pixels);               
 /* ---- multi-GPU plumbing (no reference counterpart) ------------------------------------
  * Device pointers of the context's buffers so a collective library (RCCL through torch.distributed)
  * can reduce them in place, or externally owned buffers to render into. */
+/* What a collective library needs to merge partial frames in place (include/pcr_dist.h does it with RCCL): the HIP stream
+ * the context enqueues on, its device ordinal and the length of each framebuffer in 64-bit words. */
+void *pcr_get_stream(pcr_ctx *ctx);
+int pcr_get_device(const pcr_ctx *ctx);
+size_t pcr_framebuffer_elems(const pcr_ctx *ctx);
 void *pcr_device_framebuffer(pcr_ctx *ctx);
 void *pcr_device_rg(pcr_ctx *ctx);
 void *pcr_device_ba(pcr_ctx *ctx);

@@ -62,6 +62,25 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+DIST_LIB = os.path.join(PKG_DIR, "libpcr_dist.so")
+RENDER_DIST_BIN = os.path.join(PKG_DIR, "pcr_render_dist")
+
+
+def build_dist(force: bool = False) -> str:
+    """libpcr_dist.so (include/pcr_dist.h): the multi-GPU layer in C++ over RCCL, and its headless driver pcr_render_dist."""
+    build_hip(force)
+    build_host(force)
+    srcs = [os.path.join(CSRC, "pcr_dist.cpp"), os.path.join(INCLUDE, "pcr_dist.h"), os.path.join(INCLUDE, "pcr_hip.h"), HIP_LIB]
+    if force or _stale(DIST_LIB, srcs):
+        _run([_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, srcs[0], "-o", DIST_LIB,
+              "-L", PKG_DIR, "-lpcr_hip", "-lrccl", "-Wl,-rpath,$ORIGIN"])
+    dsrc = [os.path.join(CSRC, "pcr_render_dist.cpp"), DIST_LIB, HOST_LIB]
+    if force or _stale(RENDER_DIST_BIN, dsrc):
+        _run([_hipcc(), "-O2", "-std=c++17", "-I", INCLUDE, "-I", CSRC, dsrc[0], "-o", RENDER_DIST_BIN,
+              "-L", PKG_DIR, "-lpcr_dist", "-lpcr_hip", "-lpcr_host", "-lrccl", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+    return DIST_LIB
+
+
 RENDER_BIN = os.path.join(PKG_DIR, "pcr_render")
 PREPROCESS_BIN = os.path.join(PKG_DIR, "pcr_preprocess")
 
@@ -86,6 +105,7 @@ def build_all(force: bool = False) -> None:
     build_host(force)
     build_hip(force)
     build_tools(force)
+    build_dist(force)
 
 
 if __name__ == "__main__":

@@ -1020,6 +1020,9 @@ int pcr_read_rgba(pcr_ctx *c, uint32_t *host, size_t n)
 }
 
 // ---- multi-GPU plumbing ------------------------------------------------------------------------
+void *pcr_get_stream(pcr_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int pcr_get_device(const pcr_ctx *c) { return c ? c->device : -1; }
+size_t pcr_framebuffer_elems(const pcr_ctx *c) { return c ? c->fb_elems : 0; }
 void *pcr_device_framebuffer(pcr_ctx *c) { return c ? c->fb : nullptr; }
 void *pcr_device_rg(pcr_ctx *c) { return c ? c->rg : nullptr; }
 void *pcr_device_ba(pcr_ctx *c) { return c ? c->ba : nullptr; }
