@@ -53,6 +53,10 @@ def parse_args():
                     help="multi-GPU exchange of the basic method: min-reduce the partial framebuffers to rank 0 (the display "
                          "rank), all-reduce them, or all-to-all slices + local min/resolve + all-gather of the image")
     ap.add_argument("--pipelined", action="store_true", help="N > 1: merge of frame k on a second stream under the render of frame k+1")
+    ap.add_argument("--transport", choices=["auto", "rccl", "torch"], default="auto",
+                    help="N > 1: who calls RCCL. rccl = the C++ layer (include/pcr_dist.h: ncclUint64 min in place on the context's "
+                         "stream); torch = torch.distributed collectives on torch-owned int64 frames; auto = rccl after one frame of "
+                         "each has produced the same merged framebuffer on rank 0, torch otherwise")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the second pass with the other stream layout")
@@ -156,18 +160,68 @@ def main():
 
     t_load = load(args.layout)
 
-    frame, pipe = None, None
+    frame, pipe, native = None, None, None
+    transport, transport_check = ("single GPU", None)
+
+    def torch_step_setup():
+        """Frames owned by torch (int64-mergeable), collectives through torch.distributed, everything on torch's current stream."""
+        fr = pdist.SlicedFrame(ctx, args.width, args.height, dev, world) if (args.merge == "a2a" and args.method == "basic") \
+            else pdist.DeviceFrame(ctx, args.width, args.height, dev)
+        fr.bind()
+        ctx.clear()
+        st = (lambda: pdist.render_basic_sharded(ctx, fr, p, world, merge=args.merge)) if args.method == "basic" else \
+             (lambda: pdist.render_hqs_sharded(ctx, fr, p, world, merge=args.merge))
+        return fr, st
+
     if use_dist and args.method == "basic" and args.pipelined:
         pipe = pdist.PipelinedBasicRenderer(ctx, args.width, args.height, dev, merge=args.merge)   # merge of frame k overlaps render k+1
         step = lambda: pipe.step(p)
+        transport = "torch.distributed (pipelined)"
+    elif use_dist:
+        import hashlib
+        import numpy as np
+        want_native = args.transport in ("auto", "rccl") and args.merge != "a2a"
+        root = -1 if args.merge == "allreduce" else 0
+        native_hash = None
+        if want_native:
+            try:
+                native = pdist.NativeDist(ctx, rank, world, dev)
+                native_step = (lambda: native.frame_basic(p, root)) if args.method == "basic" else (lambda: native.frame_hqs(p, root))
+                native_step()
+                ctx.synchronize()
+                native_hash = hashlib.sha256(ctx.read_framebuffer(full=True).tobytes()).hexdigest() if rank == 0 else ""
+            except Exception as e:                       # RCCL not loadable / communicator refused: the torch transport still runs
+                native, transport_check = None, "C++ RCCL layer unavailable: %s" % e
+        ok = torch.tensor([1 if native is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks or none
+        if not int(ok.item()):
+            if native is not None:
+                native.close()
+            native = None
+        if native is not None and args.transport == "auto":
+            frame, tstep = torch_step_setup()
+            tstep()
+            ctx.synchronize(); torch.cuda.synchronize()
+            same = torch.tensor([1], device=dev)
+            if rank == 0:
+                torch_hash = hashlib.sha256(ctx.read_framebuffer(full=True).tobytes()).hexdigest()
+                same[0] = 1 if torch_hash == native_hash else 0
+            dist.broadcast(same, 0)
+            frame.release(); frame = None
+            if int(same.item()):
+                transport_check = "one frame merged by the C++ layer and one merged through torch.distributed: identical u64 framebuffers on rank 0"
+            else:
+                transport_check = "C++ layer and torch.distributed disagreed on rank 0's merged framebuffer: torch transport used"
+                native.close(); native = None
+        if native is not None:
+            step = native_step
+            transport = "RCCL from C++ (include/pcr_dist.h: ncclUint64 %s, in place on the context's stream)" % ("min" if args.method == "basic" else "min / sum")
+        else:
+            frame, step = torch_step_setup()
+            transport = "torch.distributed (int64-mergeable frames)"
     else:
-        if use_dist:
-            frame = pdist.SlicedFrame(ctx, args.width, args.height, dev, world) if (args.merge == "a2a" and args.method == "basic") \
-                else pdist.DeviceFrame(ctx, args.width, args.height, dev)
-            frame.bind()
-            ctx.clear()
-        step = (lambda: pdist.render_basic_sharded(ctx, frame, p, world, merge=args.merge)) if args.method == "basic" else \
-               (lambda: pdist.render_hqs_sharded(ctx, frame, p, world, merge=args.merge))
+        step = (lambda: pdist.render_basic_sharded(ctx, None, p, world, merge=args.merge)) if args.method == "basic" else \
+               (lambda: pdist.render_hqs_sharded(ctx, None, p, world, merge=args.merge))
 
     def fence():
         if pipe is not None:
@@ -331,6 +385,7 @@ def main():
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
                        "parallelism": ("batch-sharded x%d + RCCL %s%s" % (world, merge_desc, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
+                       "transport": transport, "transport_check": transport_check,
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "preroll_s": args.preroll,
                        "first_frame_ms": round(first_frame_ms, 3)},
             "step_ms": {"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4), "max": round(max(step_ms), 4),
@@ -347,6 +402,8 @@ def main():
         pipe.release()
     if frame is not None:
         frame.release()
+    if native is not None:
+        native.close()
     ctx.close()
     if use_dist:
         dist.barrier()              # rank 0 was busy measuring and printing: leave together

@@ -325,3 +325,53 @@ class PipelinedBasicRenderer:
     def release(self):
         self.finish()
         self.frames[0].release()
+
+
+class NativeDist:
+    """include/pcr_dist.h through ctypes: the C++ multi-GPU layer (libpcr_dist.so, RCCL's own ncclUint64 min / sum on the
+    context's framebuffers and stream). torch.distributed only carries the 128-byte communicator id from rank 0 to the other
+    ranks -- the launcher's job, whatever launcher it is."""
+
+    def __init__(self, ctx, rank: int, world: int, device, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _native as N
+        from . import build
+        N.hip_lib()                                  # torch's HIP / RCCL copies first (one runtime per process)
+        lib = C.CDLL(build.DIST_LIB)
+        lib.pcr_dist_last_error.restype = C.c_char_p
+        lib.pcr_dist_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.pcr_dist_destroy.argtypes = [C.c_void_p]
+        lib.pcr_dist_destroy.restype = None
+        for n in ("pcr_dist_merge_min", "pcr_dist_merge_sum"):
+            getattr(lib, n).argtypes = [C.c_void_p, C.c_int]
+        for n in ("pcr_dist_frame_basic", "pcr_dist_frame_hqs"):
+            getattr(lib, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.lib, self.ctx, self.rank, self.world, self._C = lib, ctx, rank, world, C
+        ident = C.create_string_buffer(128)
+        if rank == 0 and lib.pcr_dist_unique_id(ident) != 0:
+            raise RuntimeError("pcr_dist_unique_id: " + lib.pcr_dist_last_error().decode())
+        t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).to(device)
+        if world > 1:
+            dist.broadcast(t, 0, group=group)
+        ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        self.h = C.c_void_p()
+        if lib.pcr_dist_create(ctx.h, ident, rank, world, C.byref(self.h)) != 0:
+            raise RuntimeError("pcr_dist_create: " + lib.pcr_dist_last_error().decode())
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(what + ": " + self.lib.pcr_dist_last_error().decode())
+
+    def frame_basic(self, params, root: int = 0):
+        """clear + prepass + shard render + u64 min merge (root, or -1 for every rank) + resolve where the frame ends up."""
+        self._chk(self.lib.pcr_dist_frame_basic(self.h, self._C.byref(params), root), "pcr_dist_frame_basic")
+
+    def frame_hqs(self, params, root: int = 0):
+        self._chk(self.lib.pcr_dist_frame_hqs(self.h, self._C.byref(params), root), "pcr_dist_frame_hqs")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.pcr_dist_destroy(self.h)
+            self.h = self._C.c_void_p()
