@@ -217,3 +217,23 @@ def test_live_reference_matches_committed_vectors(huff_vectors):
     escape_table_equal(tv, tl, v["table_values"], v["table_lens"])
     w, s, n = rc.pack(v["chain0"])
     assert np.array_equal(w, v["words0"]) and np.array_equal(s, v["separate0"]) and np.array_equal(n, v["numcw0"])
+
+
+def test_bc1_encoder_is_within_half_a_db_of_rgbcx():
+    """VERDICT r01 item 8: the native encoder's colour blocks against the reference's rgbcx::encode_bc1(level 8) blocks on the
+    committed colour set, both decoded as the kernel decodes (tools/bc1_quality.py): PSNR gap <= 0.5 dB overall and per kind."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bc1_quality as q
+    d = np.load(os.path.join(GOLD, "bc1_ref_blocks.npz"))
+    lib = N.host_lib()
+    own = np.zeros_like(d["blocks"])
+    for k in range(len(d["colors"])):
+        c = np.ascontiguousarray(d["colors"][k], np.uint32)
+        lib.pcr_bc1_encode_block(c.ctypes.data_as(C.c_void_p), own[k].ctypes.data_as(C.c_void_p))
+        c0 = int(own[k][0]) | int(own[k][1]) << 8; c1 = int(own[k][2]) | int(own[k][3]) << 8
+        assert c0 >= c1                                   # 4-colour mode (equal endpoints: every palette entry the same)
+    a, ak = q.psnr(d["colors"], own)
+    b, bk = q.psnr(d["colors"], d["blocks"])
+    assert b - a <= 0.5, (a, b)
+    assert all(y - x <= 0.5 for x, y in zip(ak, bk)), (ak, bk)
