@@ -382,6 +382,7 @@ def main():
                                       args.width, args.height,
                                       "basic atomicMin raster" if args.method == "basic" else "HQS two-pass", args.camera, args.lod, args.cull, layout_desc),
                        "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
+                       "batches_culled_rank0": int(st["batches_culled"]),
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
                        "parallelism": ("batch-sharded x%d + RCCL %s%s" % (world, merge_desc, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",

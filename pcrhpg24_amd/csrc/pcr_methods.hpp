@@ -167,6 +167,7 @@ struct HuffmanLasData : Resource {
     std::shared_ptr<LoaderTask> task;
     std::mutex mtx_state, mtx_tasks;
     std::thread reader;
+    std::string readerError;            // set by the reader thread (under mtx_tasks) when it had to give up; process() throws it
 
     ~HuffmanLasData() override { stopReader(); }
 
@@ -182,9 +183,21 @@ struct HuffmanLasData : Resource {
         batch_data_sizes.resize((size_t)numBatches);
         f.read((char *)batch_data_sizes.data(), 8 * numBatches);
         if (!f) throw std::runtime_error(path + ": shorter than its batch size table");
-        batch_data_sizes_prefix = batch_data_sizes;
-        for (int64_t i = 1; i < numBatches; ++i) batch_data_sizes_prefix[(size_t)i] += batch_data_sizes_prefix[(size_t)i - 1];
         offsetToBatchData = 40 + 8 * numBatches;
+        // every record at least its fixed part, and all of them inside the file (the reference trusts these, HuffmanLasLoader.h:
+        // 72-84; a negative or huge entry would otherwise end in an allocation failure inside the reader thread)
+        f.seekg(0, std::ios::end);
+        const int64_t fileBytes = (int64_t)f.tellg();
+        const int64_t minRecord = PCR_BATCH_FIXED_HEADER + 4 * (3072 + 1024 + 4096 + 4096 + 32) + PCR_COLOR_BYTES_PER_BATCH;
+        batch_data_sizes_prefix = batch_data_sizes;
+        int64_t running = 0;
+        for (int64_t i = 0; i < numBatches; ++i) {
+            const int64_t sz = batch_data_sizes[(size_t)i];
+            if (sz < minRecord || sz > fileBytes) throw std::runtime_error(path + ": batch " + std::to_string(i) + " has record size " + std::to_string(sz));
+            running += sz;
+            if (offsetToBatchData + running > fileBytes) throw std::runtime_error(path + ": batch records exceed the file");
+            batch_data_sizes_prefix[(size_t)i] = running;
+        }
     }
 
     static std::shared_ptr<HuffmanLasData> create(const std::string &path)   // HuffmanLasLoader.h:87-92
@@ -206,8 +219,11 @@ struct HuffmanLasData : Resource {
         renderer->check(pcr_stream_begin(renderer->ctx, &hdr, 0), "pcr_stream_begin");
         renderer->check(pcr_set_async_upload(renderer->ctx, asyncUpload ? 1 : 0), "pcr_set_async_upload");
         numBatchesLoaded = numPointsLoaded = numBatchesResident = 0;
+        readerError.clear();
         reader = std::thread([this] {
+          try {
             std::ifstream f(path, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot open " + path);
             int64_t remaining = numBatches, read = 0;
             while (remaining > 0) {
                 {
@@ -226,6 +242,7 @@ struct HuffmanLasData : Resource {
                     std::vector<char> buf((size_t)batch_data_sizes[(size_t)b]);
                     f.seekg(start);
                     f.read(buf.data(), (std::streamsize)buf.size());
+                    if (!f) throw std::runtime_error(path + ": short read on batch " + std::to_string(b));
                     t->buffers.push_back(std::move(buf));
                     t->batchIndices.push_back(b);
                 }
@@ -236,13 +253,21 @@ struct HuffmanLasData : Resource {
             std::lock_guard<std::mutex> lock(mtx_state);
             if (state == UNLOADING) state = UNLOADED;
             else if (state == LOADING) state = LOADED;
+          } catch (const std::exception &e) {              // never let an exception leave the thread (std::terminate)
+            { std::lock_guard<std::mutex> lock(mtx_tasks); readerError = e.what(); }
+            std::lock_guard<std::mutex> lock(mtx_state);
+            state = UNLOADED;
+          }
         });
     }
 
     void process(Renderer *renderer) override               // HuffmanLasLoader.cpp:301-313
     {
         std::lock_guard<std::mutex> lock(mtx_tasks);
+        if (!readerError.empty()) { const std::string e = readerError; readerError.clear(); throw std::runtime_error("loader: " + e); }
         if (!task) return;
+        // the task is dropped whatever happens to it: a record the library rejects must not be offered again every frame
+        struct Drop { std::shared_ptr<LoaderTask> &t; ~Drop() { t = nullptr; } } drop{task};
         std::vector<const void *> blobs;
         std::vector<size_t> sizes;
         for (size_t i = 0; i < task->batchIndices.size(); ++i) { blobs.push_back(task->buffers[i].data()); sizes.push_back(task->buffers[i].size()); }
@@ -250,7 +275,6 @@ struct HuffmanLasData : Resource {
                         "pcr_upload_batches");
         numBatchesLoaded = pcr_batches_loaded(renderer->ctx);
         numPointsLoaded = pcr_points_loaded(renderer->ctx);
-        task = nullptr;
     }
 
     void unload(Renderer *renderer) override                // HuffmanLasLoader.cpp:152-174

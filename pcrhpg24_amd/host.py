@@ -34,6 +34,7 @@ ENCODED_PAD_WORDS = 1024
 SEPARATE_PAD_WORDS = 256
 BATCH_FIXED_HEADER = 124
 _BATCH_FIXED = BATCH_FIXED_HEADER + 4 * (3072 + 1024 + 4096 + 4096 + 32)
+PCR_COLOR_BYTES = 32768             # BC1: 8 bytes per 16 points
 
 
 class PcrError(RuntimeError):
@@ -201,6 +202,8 @@ class HuffmanFile:
         if self.numBatches < 0 or len(self.buf) < 40 + 8 * self.numBatches:
             raise PcrError("file shorter than its batch size table")
         self.batch_data_sizes = np.frombuffer(self.buf, np.int64, self.numBatches, 40)
+        if self.numBatches and int(self.batch_data_sizes.min()) < _BATCH_FIXED + PCR_COLOR_BYTES:
+            raise PcrError("a batch record is shorter than its fixed part (size table entry %d)" % int(self.batch_data_sizes.min()))
         self.offsetToBatchData = 40 + 8 * self.numBatches
         self.batch_offsets = self.offsetToBatchData + np.concatenate([[0], np.cumsum(self.batch_data_sizes)])
         if int(self.batch_offsets[-1]) > len(self.buf):

@@ -175,3 +175,22 @@ def test_preprocess_cli_gpu_equals_cpu(tmp_path):
         res = subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "in.las"), str(bb), "1", "--gpu", *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert res.returncode == 0, res.stderr
         assert a.read_bytes() == bb.read_bytes()
+
+
+@pytest.mark.parametrize("damage", ["negative size", "truncated"])
+def test_render_cli_reports_a_damaged_file_instead_of_terminating(tmp_path, damage):
+    """the size table is validated when the header is read, and an error inside the reader thread is handed
+    to the frame loop (exit code 1 and a message) instead of ending in std::terminate. Needs no GPU: both checks come first."""
+    build.build_tools()
+    image, _ = scenes.synth_stream(10_000)
+    data = bytearray(image.view())
+    if damage == "negative size":
+        data[40:48] = struct.pack("<q", -5)
+    else:
+        data = data[:len(data) // 2]
+    path = tmp_path / "bad.huffman"
+    path.write_bytes(bytes(data))
+    res = subprocess.run([build.RENDER_BIN, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert res.returncode == 1 and "pcr_render:" in res.stderr and "terminate" not in res.stderr
+    assert ("record size" in res.stderr) or ("exceed the file" in res.stderr) or ("no HIP device" in res.stderr and damage == "truncated") \
+        or "Renderer" in res.stderr or "pcr_create" in res.stderr

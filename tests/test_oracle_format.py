@@ -201,6 +201,10 @@ def test_malformed_files_are_rejected():
         oracle.OracleFile(bytes(geo))
     with pytest.raises(P.PcrError):
         P.HuffmanFile(good[:30])
+    # a size table entry that is negative or smaller than a record's fixed part: refused when the file is opened
+    for size in (-1, 100):
+        with pytest.raises(P.PcrError, match="shorter than its fixed part"):
+            P.HuffmanFile(good[:40] + struct.pack("<q", size) + good[48:])
 
 
 def test_lod_and_cull_decisions():
