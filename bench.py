@@ -11,7 +11,8 @@ decoded and rasterized, stream resident in HBM in the context's defa
 At N > 1 (configs[3]): 2e9 points in total, chunks sharded contiguously over the ranks (strong scaling over N = 2, 4, 8;
 --points P makes it P points per GPU instead), every step ending with the merge of the partial framebuffers over RCCL:
 by default a min-reduce of the u64 frame to the display rank (--merge a2a / allreduce: the other forms).
-A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM.
+A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM (one GPU: the resolve of a
+frame, the clear and the next frame's cull/LOD prepass share one launch, pcr_frame_turn).
 Before the W warm-up steps the frame loop runs for --preroll seconds (not counted as warm-up, not timed): the clocks of a
 fresh box settle in that time, so a 20-step run reports what a 200-step run reports.
 Prints ONE JSON line on rank 0.
@@ -214,14 +215,24 @@ def main():
                 transport_check = "C++ layer and torch.distributed disagreed on rank 0's merged framebuffer: torch transport used"
                 native.close(); native = None
         if native is not None:
-            step = native_step
+            step = (lambda: native.step_basic(p, root)) if args.method == "basic" else native_step
             transport = "RCCL from C++ (include/pcr_dist.h: ncclUint64 %s, in place on the context's stream)" % ("min" if args.method == "basic" else "min / sum")
         else:
             frame, step = torch_step_setup()
             transport = "torch.distributed (int64-mergeable frames)"
     else:
-        step = (lambda: pdist.render_basic_sharded(ctx, None, p, world, merge=args.merge)) if args.method == "basic" else \
-               (lambda: pdist.render_hqs_sharded(ctx, None, p, world, merge=args.merge))
+        # One GPU: the steady frame loop is two launches per frame -- k_render (twice for HQS), then pcr_frame_turn = the
+        # reference's RESOLVE + CLEAR (huffman_hqs.h:240-270) fused with the next frame's cull/LOD prepass. Same work as
+        # clear + render + resolve, rotated: the loop is primed with one pcr_frame_begin (timed_run does it).
+        if args.method == "basic":
+            def step():
+                ctx.render_basic(p)
+                ctx.frame_turn(p, p)
+        else:
+            def step():
+                ctx.render_hqs_depth(p)
+                ctx.render_hqs_color(p)
+                ctx.frame_turn(p, p, hqs=True)
 
     def fence():
         if pipe is not None:
@@ -236,6 +247,8 @@ def main():
 
     def timed_run(steps, warmup, preroll_s, kernel_events=True):
         """(elapsed seconds of `steps` steps between fences, average k_render ms, launches timed, first-frame ms)."""
+        if not use_dist or (native is not None and args.method == "basic"):
+            ctx.frame_begin(p, hqs=args.method == "hqs")     # primes the turn-based loops (clear + prepass); untimed
         fence()
         t0 = time.perf_counter()
         step()

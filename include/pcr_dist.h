@@ -65,6 +65,10 @@ int pcr_dist_merge_sum(pcr_dist *d, int root);          /* RG and BA: u64 sum */
  * *_finish halves; pcr_dist_frame_basic / _hqs do all three for the one-process-per-GPU case. */
 int pcr_dist_frame_basic(pcr_dist *d, const pcr_render_params *p, int root);
 int pcr_dist_frame_hqs(pcr_dist *d, const pcr_render_params *p, int root);
+/* The basic frame in its steady-state form: render + merge + one launch for resolve, CLEAR and the next frame's prepass
+ * (pcr_frame_turn) on the ranks that hold the result, CLEAR + prepass on the others. Prime the loop with one
+ * pcr_frame_begin(ctx, p, PCR_METHOD_BASIC) per rank; the merged u64 framebuffer is empty after the step (the image is not). */
+int pcr_dist_step_basic(pcr_dist *d, const pcr_render_params *p, int root);
 
 #ifdef __cplusplus
 }

@@ -197,6 +197,11 @@ const char *pcr_kernel_version(void);
 #define PCR_METHOD_BASIC 0
 #define PCR_METHOD_HQS 1
 int pcr_frame_begin(pcr_ctx *ctx, const pcr_render_params *params, int method);
+/* The reference's RESOLVE + CLEAR at the end of a frame (huffman_hqs.h:240-270) and pcr_frame_begin's prepass for the next
+ * frame, in ONE launch and one pass over the framebuffer: pcr_resolve_basic / pcr_resolve_hqs with the flags of `done`, then
+ * pcr_frame_begin(next, method). The image is where pcr_resolve_* leaves it (pcr_read_rgba); the u64 framebuffer is empty
+ * afterwards, so read it first if it is wanted. A steady frame loop is then two launches: pcr_render_*, pcr_frame_turn. */
+int pcr_frame_turn(pcr_ctx *ctx, const pcr_render_params *done, const pcr_render_params *next, int method);
 
 /* Multi-GPU merges through a library that only has a SIGNED 64-bit MIN (RCCL as torch.distributed exposes it): with
  * on = 1, pcr_clear writes INT64_MAX (0x7FFF...F) into empty pixels instead of the reference's all-ones word. Every key a

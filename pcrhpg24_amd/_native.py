@@ -76,7 +76,7 @@ HIP_SYMBOLS = [
     "pcr_read_accum", "pcr_read_rgba", "pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba",
     "pcr_use_external_buffers", "pcr_merge_min", "pcr_merge_sum", "pcr_flip_sign", "pcr_timing_begin",
     "pcr_timing_end", "pcr_kernel_timing_enable", "pcr_kernel_timing_read", "pcr_measure_hbm",
-    "pcr_frame_begin", "pcr_set_stream_layout", "pcr_set_render_variant", "pcr_set_int64_mergeable", "pcr_fence_record", "pcr_fence_wait", "pcr_merge_min_slices", "pcr_resolve_basic_range", "pcr_set_async_upload", "pcr_batches_resident", "pcr_last_frame_batches", "pcr_stream_algorithmic_bytes", "pcr_stream_resident_bytes", "pcr_kernel_version", "pcr_get_stream", "pcr_get_device", "pcr_framebuffer_elems",
+    "pcr_frame_begin", "pcr_frame_turn", "pcr_set_stream_layout", "pcr_set_render_variant", "pcr_set_int64_mergeable", "pcr_fence_record", "pcr_fence_wait", "pcr_merge_min_slices", "pcr_resolve_basic_range", "pcr_set_async_upload", "pcr_batches_resident", "pcr_last_frame_batches", "pcr_stream_algorithmic_bytes", "pcr_stream_resident_bytes", "pcr_kernel_version", "pcr_get_stream", "pcr_get_device", "pcr_framebuffer_elems",
     "pcr_las_begin", "pcr_las_upload", "pcr_las_unload", "pcr_las_batches_loaded", "pcr_render_las", "pcr_resolve_las",
     "pcr_las_algorithmic_bytes", "pcr_gpu_encode_points", "pcr_gpu_encode_free",
 ]
@@ -152,6 +152,7 @@ def hip_lib() -> C.CDLL:
         lib.pcr_timing_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.pcr_measure_hbm.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.pcr_frame_begin.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int]
+        lib.pcr_frame_turn.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(RenderParams), C.c_int]
         lib.pcr_kernel_version.restype = C.c_char_p
         lib.pcr_kernel_version.argtypes = []
         lib.pcr_stream_resident_bytes.restype = C.c_int64

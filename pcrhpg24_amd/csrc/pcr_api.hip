@@ -821,6 +821,52 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     return PCR_OK;
 }
 
+static int launch_resolve(pcr_ctx *c, const pcr_render_params *p, bool hqs);
+
+// The end of one frame and the start of the next in one launch: resolve (flags of p_done) -> d_rgba, CLEAR, and the cull/LOD
+// prepass for p_next. Equivalent to pcr_resolve_* followed by pcr_frame_begin(p_next); the framebuffer is empty afterwards
+// (read it before, if it is wanted: the depth dump does), the image is in pcr_read_rgba as after pcr_resolve_*.
+int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render_params *p_next, int method)
+{
+    int rc = check_params(c, p_next);
+    if (rc) return rc;
+    if (!p_done) return set_err(c, PCR_E_ARG, "params of the finished frame are NULL");
+    if (p_done->width != c->width || p_done->height != c->height) return set_err(c, PCR_E_ARG, "params image size != framebuffer");
+    if (method != PCR_METHOD_BASIC && method != PCR_METHOD_HQS) return set_err(c, PCR_E_ARG, "unknown method %d", method);
+    const bool hqs = method == PCR_METHOD_HQS;
+    if (hqs && (!c->rg || !c->ba)) return set_err(c, PCR_E_ARG, "no RG/BA accumulation buffers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->async_upload) poll_loader(c, false);
+    const int64_t nB = c->visible_batches();
+    if (nB == 0) {                                   // nothing to prepare: the two separate steps
+        if ((rc = launch_resolve(c, p_done, hqs))) return rc;
+        return pcr_clear(c);
+    }
+    if (!hqs && c->accum_dirty) {                    // a basic frame behind an HQS one: RG/BA are zeroed by the ordinary CLEAR
+        if ((rc = launch_resolve(c, p_done, false))) return rc;
+        return pcr_frame_begin(c, p_next, method);
+    }
+    if (!c->async_upload) enqueue_transcode(c, true, c->stream);
+    maybe_finalize(c);
+    RenderArgs a = make_args(c, p_next, hqs);
+    a.win_pixel_bytes = WIN_PIXEL_BYTES;
+    a.dyn_lds_bytes = frame_dyn_lds(c, nB);
+    c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
+    const unsigned grid = (unsigned)c->stats_partials + 2048u;
+    const uint32_t pixels = (uint32_t)((size_t)c->width * c->height);
+    if (hqs) hipLaunchKernelGGL(k_frame_turn<true>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+                                p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key);
+    else     hipLaunchKernelGGL(k_frame_turn<false>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+                                p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key);
+    HIP_TRY(c, hipGetLastError());
+    c->accum_dirty = false;
+    c->prepass_ready = true;
+    c->prepass_params = *p_next; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_pixel_bytes = a.win_pixel_bytes;
+    c->prepass_dyn_lds = a.dyn_lds_bytes;
+    c->prepass_batches = nB;
+    return PCR_OK;
+}
+
 int pcr_set_int64_mergeable(pcr_ctx *c, int on)
 {
     if (!c) return PCR_E_ARG;

@@ -151,6 +151,20 @@ int pcr_dist_frame_basic(pcr_dist *d, const pcr_render_params *p, int root)
     return PCR_OK;
 }
 
+// Steady-state form of pcr_dist_frame_basic: the frame's CLEAR + prepass were done by the previous step (or by one
+// pcr_frame_begin before the first), so a step is shard render + merge + ONE launch that resolves the merged frame where it
+// ended up, clears, and runs the next frame's prepass (pcr_frame_turn); ranks that hold no result only clear + prepass.
+int pcr_dist_step_basic(pcr_dist *d, const pcr_render_params *p, int root)
+{
+    if (!d || !p) return fail(PCR_E_ARG, "bad arguments");
+    PCR_TRY(d, pcr_render_basic(d->ctx, p));
+    int rc = pcr_dist_merge_min(d, root);
+    if (rc) return rc;
+    if (root == PCR_DIST_ALL || root == d->rank) PCR_TRY(d, pcr_frame_turn(d->ctx, p, p, PCR_METHOD_BASIC));
+    else                                         PCR_TRY(d, pcr_frame_begin(d->ctx, p, PCR_METHOD_BASIC));
+    return PCR_OK;
+}
+
 int pcr_dist_frame_hqs(pcr_dist *d, const pcr_render_params *p, int root)
 {
     if (!d || !p) return fail(PCR_E_ARG, "bad arguments");

@@ -1353,6 +1353,45 @@ __global__ void __launch_bounds__(256) k_resolve(int show_num_points, int colori
     rgba[pix] = color;
 }
 
+// RESOLVE of the finished frame, CLEAR for the next one and the next frame's cull/LOD prepass in ONE launch (pcr_frame_turn):
+// the reference's frame ends with resolve + clear (huffman_hqs.h:240-270); done separately they are two passes over the
+// framebuffer and two launches (21 us of a 269 us frame at 1080p), fused one pass reads every word once, writes the pixel,
+// and writes the empty word back. The first `prepass_blocks` workgroups do the prepass instead (it touches no framebuffer).
+// Same arithmetic as k_resolve<HQS>; pixels are walked linearly (the resolve is per pixel, the tile shape does not matter).
+template <bool HQS>
+__global__ void __launch_bounds__(256) k_frame_turn(RenderArgs a, uint32_t prepass_blocks, int show_num_points, int colorize_chunks,
+                                                    uint32_t pixels, uint64_t *fb, uint64_t *rg, uint64_t *ba, uint32_t *rgba,
+                                                    uint32_t n, uint64_t empty)
+{
+    if (blockIdx.x < prepass_blocks) { lod_prepass_block(a, blockIdx.x); return; }
+    const uint32_t stride = (gridDim.x - prepass_blocks) * 256u;
+    for (uint32_t i = (blockIdx.x - prepass_blocks) * 256u + threadIdx.x; i < n; i += stride) {
+        if (i < pixels) {
+            const uint32_t id = (uint32_t)fb[i];
+            uint32_t color = PCR_BACKGROUND_COLOR;
+            if (id < 0xFFFFFFFFu) {
+                if (show_num_points) {
+                    const double div = HQS ? 512.0 : 64.0;
+                    const uint32_t shade = (uint32_t)(((double)(float)(int)id / div) * 255.0);
+                    color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+                } else if (colorize_chunks) {
+                    color = id * 1234567u;
+                } else if (HQS) {
+                    const uint64_t vrg = rg[i], vba = ba[i];
+                    const uint32_t cnt = (uint32_t)vba;
+                    if (cnt == 0) color = 0;
+                    else color = (((uint32_t)(vba >> 32) / cnt) << 16) | (((uint32_t)vrg / cnt) << 8) | ((uint32_t)(vrg >> 32) / cnt);
+                } else {
+                    color = id;
+                }
+            }
+            rgba[i] = color;
+        }
+        fb[i] = empty;
+        if (HQS) { rg[i] = 0; ba[i] = 0; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-GPU merges
 // ------------------------------------------------------------------------------------------------

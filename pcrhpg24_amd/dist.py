@@ -346,7 +346,7 @@ class NativeDist:
         lib.pcr_dist_destroy.restype = None
         for n in ("pcr_dist_merge_min", "pcr_dist_merge_sum"):
             getattr(lib, n).argtypes = [C.c_void_p, C.c_int]
-        for n in ("pcr_dist_frame_basic", "pcr_dist_frame_hqs"):
+        for n in ("pcr_dist_frame_basic", "pcr_dist_frame_hqs", "pcr_dist_step_basic"):
             getattr(lib, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         self.lib, self.ctx, self.rank, self.world, self._C = lib, ctx, rank, world, C
         ident = C.create_string_buffer(128)
@@ -370,6 +370,10 @@ class NativeDist:
 
     def frame_hqs(self, params, root: int = 0):
         self._chk(self.lib.pcr_dist_frame_hqs(self.h, self._C.byref(params), root), "pcr_dist_frame_hqs")
+
+    def step_basic(self, params, root: int = 0):
+        """render + merge + (resolve, clear, next prepass in one launch); prime with ctx.frame_begin(params) once."""
+        self._chk(self.lib.pcr_dist_step_basic(self.h, self._C.byref(params), root), "pcr_dist_step_basic")
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -370,6 +370,10 @@ class Context:
         """pcr_clear + the prepass of the render call that follows, in one launch (pcr_hip.h)."""
         self._chk(self.lib.pcr_frame_begin(self.h, C.byref(p), 1 if hqs else 0), "pcr_frame_begin")
 
+    def frame_turn(self, done: RenderParams, nxt: RenderParams, hqs: bool = False):
+        """Resolve the finished frame, clear, and run the next frame's prepass in one launch (pcr_frame_turn)."""
+        self._chk(self.lib.pcr_frame_turn(self.h, C.byref(done), C.byref(nxt), 1 if hqs else 0), "pcr_frame_turn")
+
     def render_basic(self, p: RenderParams):
         self._chk(self.lib.pcr_render_basic(self.h, C.byref(p)), "pcr_render_basic")
 

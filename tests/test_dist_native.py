@@ -80,6 +80,13 @@ def test_one_rank_communicator_frames_match_the_oracle():
             assert lib.pcr_dist_frame_basic(d, C.byref(p), root) == 0, lib.pcr_dist_last_error()
             assert np.array_equal(r.ctx.read_framebuffer(full=True), ofb) and r.ctx.stats() == ost
             assert np.array_equal(r.ctx.read_rgba(), oracle.resolve_basic(p, ofb))
+        # steady-state form: render + merge + one launch for resolve / clear / next prepass
+        lib.pcr_dist_step_basic.argtypes = [C.c_void_p, C.POINTER(P.RenderParams), C.c_int]
+        r.ctx.frame_begin(p)
+        for _ in range(2):
+            assert lib.pcr_dist_step_basic(d, C.byref(p), 0) == 0, lib.pcr_dist_last_error()
+            assert np.array_equal(r.ctx.read_rgba(), oracle.resolve_basic(p, ofb)) and r.ctx.stats() == ost
+        r.ctx.clear()
         hfb, _ = of.render_hqs_depth(p)
         org, oba, _ = of.render_hqs_color(p, hfb)
         assert lib.pcr_dist_frame_hqs(d, C.byref(p), 0) == 0, lib.pcr_dist_last_error()

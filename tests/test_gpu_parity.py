@@ -356,3 +356,45 @@ def test_frame_begin_equals_clear_then_prepass(renderer, stream2m):
     assert ctx.stats() == hst
     assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
     _check_basic(ctx, of, p)
+
+
+def test_frame_turn_equals_resolve_then_frame_begin(renderer, stream2m):
+    """pcr_frame_turn = pcr_resolve_* of the finished frame + pcr_clear + the next frame's prepass, one launch: the image it
+    leaves is the resolve's, the framebuffer is empty, the next render (same or other parameters) draws the oracle's frame;
+    debug payload flags of the finished frame are honoured; a basic turn behind an HQS frame still zeroes RG/BA."""
+    nb, of = stream2m
+    _load(renderer, nb)
+    ctx = renderer.ctx
+    cams = scenes.cameras(W, H)
+    p = scenes.with_flags(cams["overview"], lod_percent=100, cull=0)
+    q = scenes.with_flags(cams["closeup"], lod_percent=10, cull=1)
+    empty = np.uint64(0xFFFFFFFFFFFFFFFF)
+    ctx.frame_begin(p)
+    for done, nxt in ((p, p), (p, q), (q, q), (q, p)):
+        ctx.render_basic(done)
+        ofb, ost = of.render_basic(done)
+        assert ctx.stats() == ost
+        ctx.frame_turn(done, nxt)
+        assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(done, ofb))
+        assert (ctx.read_framebuffer(full=True) == empty).all()
+    ctx.render_basic(p)                                     # the prepass prepared by the last turn (for p) is the one used here
+    assert np.array_equal(ctx.read_framebuffer(full=True), of.render_basic(p)[0])
+    # HQS frames through turns
+    ctx.clear(); ctx.frame_begin(q, hqs=True)
+    for done, nxt in ((q, p), (p, q)):
+        ctx.render_hqs_depth(done)
+        hfb, _ = of.render_hqs_depth(done)
+        assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
+        ctx.render_hqs_color(done)
+        org, oba, _ = of.render_hqs_color(done, hfb)
+        ctx.frame_turn(done, nxt, hqs=True)
+        assert np.array_equal(ctx.read_rgba(), oracle.resolve_hqs(done, hfb, org, oba))
+        rg, ba = ctx.read_accum(full=True)
+        assert (ctx.read_framebuffer(full=True) == empty).all() and not rg.any() and not ba.any()
+    # a basic turn right behind an HQS colour pass: RG/BA must come out zeroed as well
+    ctx.render_hqs_depth(q); ctx.render_hqs_color(q)
+    ctx.frame_turn(scenes.with_flags(q, colorize_chunks=1), p)
+    rg, ba = ctx.read_accum(full=True)
+    assert not rg.any() and not ba.any()
+    ctx.render_basic(p)
+    assert np.array_equal(ctx.read_framebuffer(full=True), of.render_basic(p)[0])
