@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORD = os.path.join(ROOT, "profiles", "r01_v30_bench_basic.json")
+RECORD = os.path.join(ROOT, "profiles", "r02_bench_basic.json")
 
 
 @pytest.fixture(scope="module")
@@ -23,8 +23,9 @@ def test_required_keys_and_types(line):
     assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
     assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["data"] == "synthetic"
     assert isinstance(line["config"]["workload"], str) and "model" not in line["config"]
+    assert "decode variant point_windows" in line["config"]["workload"]   # the line says which layout / kernel variant it ran
     r = line["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_version"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     c = line["cpu_baseline"]
@@ -48,8 +49,35 @@ def test_measured_ceiling_and_traffic_are_reported(line):
     m = r["peak_measured"]
     assert m["unit"] == "GB/s" and 3000.0 < m["stream_copy"] < m["stream_read"] <= r["peak"]
     assert abs(m["frac_of_read"] - r["achieved"] / m["stream_read"]) < 1e-3
-    # the point-window layout reads more than the compressed bytes on purpose; it is reported, not hidden
-    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes"]
+    # the point-window layout reads more than the compressed bytes on purpose; it is reported, not hidden,
+    # and says where the number comes from (a PMC profile of the same kernel version, not this run)
+    assert r["traffic"] is not None and r["algorithmic_bytes"] < r["traffic"] < 3 * r["algorithmic_bytes"]
+    assert "profiles/pmc_traffic_latest.json" in r["traffic_source"] and r["kernel_version"] in r["traffic_source"]
     assert r["kernel_launches_timed"] >= 32
     one = line["cpu_baseline"]["single_core"]
     assert 0 < one["value"] < line["cpu_baseline"]["value"]
+
+
+def test_both_variants_and_the_step_distribution_are_reported(line):
+    v = line["variants"]
+    assert set(v) == {"point_windows", "words"}
+    for name, rec in v.items():
+        for key in ("ms_per_step", "kernel_ms", "frac", "resident_bytes_per_point", "hbm_bytes_read_per_point"):
+            assert key in rec, (name, key)
+        assert rec["kernel_ms"] <= rec["ms_per_step"]
+    # resident <= 9 B/point in the default layout; the packed words are the smaller, slower variant
+    assert v["point_windows"]["resident_bytes_per_point"] <= 9.0 and v["words"]["resident_bytes_per_point"] < v["point_windows"]["resident_bytes_per_point"]
+    assert v["point_windows"]["ms_per_step"] == line["ms_per_step"]
+    d = line["step_ms"]
+    assert d["n"] >= 32 and d["min"] <= d["median"] <= d["max"]
+    assert abs(d["median"] - line["ms_per_step"]) / line["ms_per_step"] < 0.05
+
+
+def test_short_and_long_runs_agree():
+    """with the clock pre-roll a 20-step run reports what the 200-step run reports (within 3 %)."""
+    with open(os.path.join(ROOT, "profiles", "r02_bench_basic20.json")) as f:
+        short = json.loads(f.read().strip().splitlines()[-1])
+    with open(RECORD) as f:
+        long_ = json.loads(f.read().strip().splitlines()[-1])
+    assert short["steps"] == 20 and long_["steps"] == 200
+    assert abs(short["ms_per_step"] - long_["ms_per_step"]) / long_["ms_per_step"] < 0.03
