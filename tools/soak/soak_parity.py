@@ -37,6 +37,8 @@ def main():
     ctxs = {}
     for (w, h) in sizes:
         ctx = P.Context(0)
+        if args.variant == "words":
+            ctx.set_stream_layout(P.Context.LAYOUT_BOTH)      # both resident, the packed-words kernel forced
         ctx.set_render_variant({"auto": 0, "words": 1, "point_windows": 2}[args.variant])
         ctx.set_image_size(w, h)
         ctx.stream_begin(hf.header(), 0)

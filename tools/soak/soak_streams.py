@@ -60,6 +60,8 @@ def main():
     rng = np.random.default_rng(args.seed)
     W, H = 480, 270
     ctx = P.Context(0)
+    if args.variant == "words":
+        ctx.set_stream_layout(P.Context.LAYOUT_BOTH)          # both resident, the packed-words kernel forced
     ctx.set_render_variant({"auto": 0, "words": 1, "point_windows": 2}[args.variant])
     ctx.set_image_size(W, H)
     bad = enc_bad = 0
