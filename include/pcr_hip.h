@@ -143,9 +143,6 @@ int   pcr_merge_sum(pcr_ctx *ctx, const void *dev_other_rg, const void *dev_othe
  * int64 MIN all-reduce (the dtype torch.distributed exposes) computes the u64 min. */
 int   pcr_flip_sign(pcr_ctx *ctx);
 
-/* ---- measurement ---------------------------------------------------------------------------------
- * HIP events on the context's stream: begin/end bracket any sequence of enqueued calls;
- * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
 /* All-to-all form of the multi-GPU merge (pcrhpg24_amd/dist.py, merge="a2a"): the frame is cut into N contiguous slices
  * of slice_elems words; after an all-to-all a rank holds everyone's copy of the slice it owns, back to back.
  * pcr_merge_min_slices leaves their element-wise min in the first slice; pcr_resolve_basic_range resolves `count` pixels of
@@ -167,9 +164,9 @@ int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
  * frame after the last batch was uploaded (pcr_upload_tail has to come before that frame).
  *   PCR_LAYOUT_WORDS          per chain the sequence of 32-bit words it consumes (320 B per chain allocated, ~3 B per
  *                             point read): the decode keeps a five-word queue per lane.
- *   PCR_LAYOUT_POINT_WINDOWS  (default) per point the 64 bits of its chain's stream that start at the point's first bit
- *                             (8 B per point): no queue in the decode, ~20 % fewer instructions per point for ~2.5x the
- *                             bytes per frame, on a kernel that is bound by instruction issue and latency, not by HBM.
+ *   PCR_LAYOUT_POINT_WINDOWS  (default) per point the 48 bits of its chain's stream that start at the point's first bit
+ *                             (6 B per point, a u32 and a u16 plane): no queue in the decode, fewer instructions per
+ *                             point for ~1.6x the bytes per frame, on a kernel bound by issue and latency, not by HBM.
  *   PCR_LAYOUT_BOTH           both resident: either decode variant can draw a frame (pcr_set_render_variant). */
 #define PCR_LAYOUT_WORDS 0
 #define PCR_LAYOUT_POINT_WINDOWS 1
@@ -223,6 +220,9 @@ int pcr_set_async_upload(pcr_ctx *ctx, int on);
 int64_t pcr_batches_resident(pcr_ctx *ctx);
 int64_t pcr_last_frame_batches(const pcr_ctx *ctx);   /* batches drawn by the last pcr_render_* call */
 
+/* ---- measurement ---------------------------------------------------------------------------------
+ * HIP events on the context's stream: begin/end bracket any sequence of enqueued calls;
+ * pcr_timing_end synchronises and returns the elapsed milliseconds between the two events. */
 int pcr_timing_begin(pcr_ctx *ctx);
 int pcr_timing_end(pcr_ctx *ctx, float *elapsed_ms);
 /* Practical HBM ceiling of this device, set beside the 8 TB/s spec peak in the roofline: best of `reps`

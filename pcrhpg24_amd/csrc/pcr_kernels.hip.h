@@ -496,10 +496,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         if (any) atomicOr(any_generic, 1u);                 // sticky, per stream: the host launches the checked kernel only if set
     }
 
-    // Point windows: 64 bits of my word sequence from each point's first bit. A point's window can reach two words past
-    // the last word the walk had fetched when the point began, so they are cut once the whole sequence is written
-    // (rows the chain never received read as what the buffer held -- bits no symbol of the point can reach).
+    // Point windows: 48 bits of my word sequence from each point's first bit. A point's window can reach two words past
+    // the last word the walk had fetched when the point began, so they are cut once the whole sequence is written. The two
+    // rows behind the chain's last word are zeroed first: no symbol can reach those bits, but the buffer may be the
+    // transcode scratch of an earlier launch and the windows should not depend on what it held.
     if (pw) {
+        out[(size_t)row * PCR_WORKGROUP_SIZE] = 0;
+        out[(size_t)(row + 1) * PCR_WORKGROUP_SIZE] = 0;
         __threadfence();            // my own stores above (lane_words column, parked positions) before I read them back
 #pragma unroll 4
         for (int i = 0; i < PW_ROWS; ++i) {
