@@ -827,13 +827,17 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // One symbol step (:430-451) of the point being decoded. `e` is the table entry of this symbol, fetched one step ahead;
     // (bits >> sft) & 0x3FFC is 4 x the 12-bit window of :431-433 (== ((L|R) & mask) >> 20) at the current position, i.e.
     // the byte offset of an entry. Returns the decoded delta.
-    auto symbol_step = [&]() __attribute__((always_inline)) -> uint32_t {
+    // esc_first (the third symbol's form): the escape word, if any, is requested BEFORE the next table entry. LDS results
+    // return in issue order, so its value can be waited for (lgkmcnt(1)) while the look-ahead entry of the next point's first
+    // symbol -- needed only at the top of the next iteration -- stays in flight.
+    auto symbol_step = [&](auto esc_first) __attribute__((always_inline)) -> uint32_t {
+        constexpr bool ESC_FIRST = decltype(esc_first)::value;
         const uint32_t e = e_ahead, toff = toff_ahead;                      // :435-436
         // :439. The whole entry is subtracted: byte 0 is the length, and only the low six bits of `sft` are ever used (the
         // 64-bit shift below takes its count modulo 64; 14 <= true sft <= 50) -- a plain v_sub_u32
         sft -= e;
         toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
-        e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
+        if (!ESC_FIRST) e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
         int32_t val = (int32_t)e >> TE_VALUE_SHIFT;                         // the delta itself (v_ashrrev_i32)
         if (val == TE_SLOW_VALUE) {                                         // escape or wide
             if (!GENERIC) {                                                 // every such entry is an escape whose word is in the pool
@@ -852,6 +856,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 asm volatile("; wide table value from global memory %0" : "+v"(val));
             }
         }
+        if (ESC_FIRST) e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
 #ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
         {
             uint32_t pad = tid;
@@ -908,16 +913,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
             in_window = rx < ww && ry < wh;
             off_window = !in_window;
-            if (MODE == MODE_HQS_COLOR) pend_w = ry * ww + rx; else pend_p = s_win + (ry * ww + rx);
+            // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
+            if (MODE == MODE_HQS_COLOR) pend_w = in_window ? ry * ww + rx : 0u; else pend_p = s_win + (in_window ? ry * ww + rx : 0u);
         }
         pend_valid = inside;
         pend_off = off_window;
-        // (two separate steps, the LDS read first: a load into the same registers issued behind it only has to wait for
-        // the LDS counter, the other way round the LDS read would wait for every vector-memory load in flight)
-        if (in_window) pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
+        // The window word is read by EVERY lane, wanted or not (a lane that is not inside re-reads its last pixel): with the
+        // read issued on every path hipcc knows how many LDS results are outstanding at the top of the next iteration and
+        // waits for the look-ahead table entry alone (lgkmcnt(1)) instead of for this read as well.
+        // (The global load comes second: a load into the same registers issued behind the LDS read only has to wait for the
+        // LDS counter, the other way round the LDS read would wait for every vector-memory load in flight.)
+        pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
         if (off_window) {
             pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
-            pend_old = g_fb[pend_pix];
+            // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
+            // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
+            pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
 
@@ -946,13 +957,15 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const uint32_t extra1 = lw_load((uint32_t)(i + 8) * LW_ROW_BYTES + tid * 4);
 #endif
 #endif
-        const uint32_t d0 = symbol_step();                                  // :430
+        constexpr std::integral_constant<bool, false> table_first{};
+        constexpr std::integral_constant<bool, true> escape_first{};
+        const uint32_t d0 = symbol_step(table_first);                       // :430
         // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
         // word has been in flight since the end of the last iteration
         // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
         if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
-        const uint32_t d1 = symbol_step();
-        const uint32_t d2 = symbol_step();
+        const uint32_t d1 = symbol_step(table_first);
+        const uint32_t d2 = symbol_step(escape_first);
         if (MODE == MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
