@@ -383,7 +383,7 @@ def main():
         merge_desc = {"reduce": "min reduce to rank 0", "allreduce": "min all-reduce",
                       "a2a": "all-to-all of frame slices + local min/resolve + all-gather of the image"}[args.merge]
     if rank == 0:
-        layout_desc = {"point_windows": "stream resident as per-point 48-bit windows (6 B/point), decode variant point_windows",
+        layout_desc = {"point_windows": "stream resident as per-point 40-bit windows (5 B/point), decode variant point_windows",
                        "words": "stream resident as lane-major packed words (~3 B/point read), decode variant words"}[args.layout]
         out = {
             "metric": "Mpoints/s decoded+rasterized @%dx%d" % (args.width, args.height),

@@ -164,9 +164,10 @@ int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
  * frame after the last batch was uploaded (pcr_upload_tail has to come before that frame).
  *   PCR_LAYOUT_WORDS          per chain the sequence of 32-bit words it consumes (320 B per chain allocated, ~3 B per
  *                             point read): the decode keeps a five-word queue per lane.
- *   PCR_LAYOUT_POINT_WINDOWS  (default) per point the 48 bits of its chain's stream that start at the point's first bit
- *                             (6 B per point, a u32 and a u16 plane): no queue in the decode, fewer instructions per
- *                             point for ~1.6x the bytes per frame, on a kernel bound by issue and latency, not by HBM.
+ *   PCR_LAYOUT_POINT_WINDOWS  (default) per point the 40 bits of its chain's stream that start at the point's first bit
+ *                             (5 B per point, a u32 and a u8 plane): no queue in the decode, a point's first table read
+ *                             off the dependent chain, fewer instructions per point for ~1.4x the bytes per frame, on a
+ *                             kernel bound by issue and latency, not by HBM.
  *   PCR_LAYOUT_BOTH           both resident: either decode variant can draw a frame (pcr_set_render_variant). */
 #define PCR_LAYOUT_WORDS 0
 #define PCR_LAYOUT_POINT_WINDOWS 1

@@ -58,7 +58,7 @@ struct pcr_ctx {
     bool any_generic_pending = false;
     uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
     uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
-    uint8_t *d_point_windows = nullptr;         // PCR_LAYOUT_POINT_WINDOWS: 48-bit view per point (k_transcode), PW_BATCH_BYTES per batch
+    uint8_t *d_point_windows = nullptr;         // PCR_LAYOUT_POINT_WINDOWS: 40-bit view per point (k_transcode), PW_BATCH_BYTES per batch
     int layout = PCR_LAYOUT_POINT_WINDOWS;      // of the stream being loaded (pcr_set_stream_layout, fixed at pcr_stream_begin)
     int next_layout = PCR_LAYOUT_POINT_WINDOWS;
     int variant = PCR_VARIANT_AUTO;             // which k_render variant draws a stream that has both layouts resident
@@ -384,7 +384,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r02.v46"; }
+const char *pcr_kernel_version(void) { return "r02.v51"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {

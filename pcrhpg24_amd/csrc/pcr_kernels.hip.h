@@ -68,18 +68,20 @@ __device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_byt
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
 constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
-// Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 48 bits of the chain's own
-// bit stream that start at the point's first bit -- its three symbols (<= 36 bits) and the look-ahead of the next point's
-// first symbol (12 more) lie inside. Stored as two planes per batch: PW_ROWS rows of 1024 x u32 (bits 0..31 of the window)
-// followed by PW_ROWS rows of 1024 x u16 (bits 32..47). Row i is read at point i by every lane of k_render (256 + 128
-// contiguous bytes per wave), with no word queue to maintain: 6 bytes per point of HBM instead of the ~3 the packed words
-// take -- bytes traded for instructions. (Round 1 stored 64 bits per point; the last 16 were never looked at.)
+// Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 40 bits of the chain's own
+// bit stream that start at the point's first bit -- its three symbols (<= 36 bits) lie inside. Stored as two planes per
+// batch: PW_ROWS rows of 1024 x u32 (bits 0..31 of the window) followed by PW_ROWS rows of 1024 x u8 (bits 32..39). Row i is
+// read at point i by every lane of k_render (256 + 64 contiguous bytes per wave), with no word queue to maintain: 5 bytes per
+// point of HBM instead of the ~3 the packed words take -- bytes traded for instructions. The key of a point's FIRST symbol is
+// the top 12 bits of its own window, which do not depend on the point before it: k_render requests that table entry a whole
+// point ahead, and only two of a point's three table reads are left on the dependent chain. (Round 1 stored 64 bits per
+// point, round 2's first form 48: 36 + the look-ahead of the next point's first symbol, which the next window holds anyway.)
 // PW_GUARD_BYTES: k_render requests two rows ahead, the last batch's low plane is followed by this much slack.
 constexpr int PW_ROWS        = PCR_POINTS_PER_THREAD;
-constexpr uint32_t PW_HI_ROW_BYTES = PCR_WORKGROUP_SIZE * 4, PW_LO_ROW_BYTES = PCR_WORKGROUP_SIZE * 2;
+constexpr uint32_t PW_HI_ROW_BYTES = PCR_WORKGROUP_SIZE * 4, PW_LO_ROW_BYTES = PCR_WORKGROUP_SIZE * 1;
 constexpr uint32_t PW_HI_BYTES = PW_ROWS * PW_HI_ROW_BYTES;                 // offset of the low plane inside a batch's block
-constexpr uint32_t PW_BATCH_BYTES = PW_ROWS * (PW_HI_ROW_BYTES + PW_LO_ROW_BYTES);   // 384 KiB
-constexpr uint32_t PW_GUARD_BYTES = 2 * PW_LO_ROW_BYTES;
+constexpr uint32_t PW_BATCH_BYTES = PW_ROWS * (PW_HI_ROW_BYTES + PW_LO_ROW_BYTES);   // 320 KiB
+constexpr uint32_t PW_GUARD_BYTES = 2 * PW_HI_ROW_BYTES;
 enum { LAYOUT_WORDS = 0, LAYOUT_POINT_WINDOWS = 1 };
 // batch_flags: set when some chain of the batch can meet an in-table value outside the packed entry's range or read an
 // escape word outside k_render's LDS pool (k_transcode walks all 192 symbols of every chain, garbage tails included)
@@ -449,9 +451,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     uint32_t ep = 64, next_cross = 2 * CHUNK_WORDS;         // already_read (:418)
     uint32_t sft = 32 + 20;                                 // cur_bits (:419) + 20: (bits >> sft) & 0xFFF is the key of :431-433
     uint32_t nesc = 0;
-    // my column of the batch's two window planes (high: u32 per point, low: u16 per point)
+    // my column of the batch's two window planes (high: u32 per point, low: u8 per point)
     uint32_t *pw = point_windows ? reinterpret_cast<uint32_t *>(point_windows + (size_t)b * PW_BATCH_BYTES) + tid : nullptr;
-    uint16_t *pwl = point_windows ? reinterpret_cast<uint16_t *>(point_windows + (size_t)b * PW_BATCH_BYTES + PW_HI_BYTES) + tid : nullptr;
+    uint8_t *pwl = point_windows ? point_windows + (size_t)b * PW_BATCH_BYTES + PW_HI_BYTES + tid : nullptr;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < PCR_POINTS_PER_THREAD * 3; ++k) {   // :428-430
@@ -496,7 +498,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         if (any) atomicOr(any_generic, 1u);                 // sticky, per stream: the host launches the checked kernel only if set
     }
 
-    // Point windows: 48 bits of my word sequence from each point's first bit. A point's window can reach two words past
+    // Point windows: 40 bits of my word sequence from each point's first bit. A point's window can reach two words past
     // the last word the walk had fetched when the point began, so they are cut once the whole sequence is written. The two
     // rows behind the chain's last word are zeroed first: no symbol can reach those bits, but the buffer may be the
     // transcode scratch of an earlier launch and the windows should not depend on what it held.
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
             const uint32_t hi = o ? __builtin_amdgcn_alignbit(a0, a1, 32u - o) : a0;
             const uint32_t lo = o ? __builtin_amdgcn_alignbit(a1, a2, 32u - o) : a1;
             pw[(size_t)i * PCR_WORKGROUP_SIZE] = hi;                     // bits 0..31 of the window
-            pwl[(size_t)i * PCR_WORKGROUP_SIZE] = (uint16_t)(lo >> 16);  // bits 32..47
+            pwl[(size_t)i * PCR_WORKGROUP_SIZE] = (uint8_t)(lo >> 24);   // bits 32..39
         }
     }
 }
@@ -657,16 +659,18 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // symbols (<= 36 bits) and the look-ahead of the next point's first symbol (12 more) index into it, and the words
     // that ran dry are retired afterwards: no refill test, load or wait inside the symbol steps.
     // (Cur/Next of :416-419 are the first two words; the stand-in w0 = 0 is "fully consumed" from the start.)
-    // LAYOUT_POINT_WINDOWS: the 64-bit view of every point was cut by k_transcode; row i of point_windows is read at
-    // point i (requested two points earlier) and there is no queue.
+    // LAYOUT_POINT_WINDOWS: the view of every point was cut by k_transcode; row i of point_windows is read at point i
+    // (requested two points earlier) and there is no queue.
     const char *lwb = reinterpret_cast<const char *>(a.s.lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE);   // uniform
     auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + byte_off); };
     const char *pwb = reinterpret_cast<const char *>(a.s.point_windows) + (size_t)b * PW_BATCH_BYTES;               // uniform
-    // the 48-bit window of a point as the top of a 64-bit view: high plane u32, low plane u16 (the 16 bits below are zero)
+    // the 40-bit window of a point as the top of a 64-bit view: high plane u32, low plane u8 (the 24 bits below are zero)
+    // (per-lane byte offsets that advance by a row: with a uniform pointer that advances instead, hipcc adds the lane's
+    // offset to it with a 64-bit vector add in front of every load)
     auto pw_load_hi = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pwb + byte_off); };
-    auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint16_t *>(pwb + byte_off); };
+    auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint8_t *>(pwb + byte_off); };
     uint32_t lwo = tid * 4;                                 // byte offset of my column in the row of far0 / in the high plane's row
-    uint32_t lwo2 = PW_HI_BYTES + tid * 2;                  // ... in the low plane's row
+    uint32_t lwo2 = PW_HI_BYTES + tid;                      // ... in the low plane's row
     uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
     uint64_t bits;
     uint32_t nwin_hi = 0, nwin_lo = 0;
@@ -676,9 +680,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         lwo += 2 * LW_ROW_BYTES;
         bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
     } else {
-        bits = ((uint64_t)pw_load_hi(lwo) << 32) | (pw_load_lo(lwo2) << 16);
+        bits = ((uint64_t)pw_load_hi(lwo) << 32) | (pw_load_lo(lwo2) << 24);
         lwo += PW_HI_ROW_BYTES; lwo2 += PW_LO_ROW_BYTES;
-        nwin_hi = pw_load_hi(lwo); nwin_lo = pw_load_lo(lwo2);
+        nwin_hi = pw_load_hi(lwo); nwin_lo = pw_load_lo(lwo2) << 24;
     }
     constexpr uint32_t SFT0 = 50;                           // (bits >> 50) & 0x3FFC = 4 x the top 12 bits of the view
     uint32_t sft = SFT0;
@@ -764,7 +768,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #define PCR_ADVANCE_WORD_WINDOW()                                                          \
     do {                                                                                   \
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {                                              \
-            bits = ((uint64_t)nwin_hi << 32) | (nwin_lo << 16);                            \
+            bits = ((uint64_t)nwin_hi << 32) | nwin_lo;                                    \
             sft = SFT0;                                                                    \
             break;                                                                         \
         }                                                                                  \
@@ -819,10 +823,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // framebuffer word of a point is requested a whole point before it is used. A deeper software pipeline (decode k+2 |
     // project k+1 | scatter k, the projection split over the second and third table read) was built and measured: +4 %,
     // hipcc spends the 64 registers on copies between the stages (profiles/r02_experiments.md).
-    float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-    float qx = 0.0f, qy = 0.0f, qw = 0.0f;
-    bool candidate = false, w_ok = true, inside = false;
-    int ix = 0, iy = 0;
 
     // One symbol step (:430-451) of the point being decoded. `e` is the table entry of this symbol, fetched one step ahead;
     // (bits >> sft) & 0x3FFC is 4 x the 12-bit window of :431-433 (== ((L|R) & mask) >> 20) at the current position, i.e.
@@ -830,14 +830,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // esc_first (the third symbol's form): the escape word, if any, is requested BEFORE the next table entry. LDS results
     // return in issue order, so its value can be waited for (lgkmcnt(1)) while the look-ahead entry of the next point's first
     // symbol -- needed only at the top of the next iteration -- stays in flight.
-    auto symbol_step = [&](auto esc_first) __attribute__((always_inline)) -> uint32_t {
-        constexpr bool ESC_FIRST = decltype(esc_first)::value;
-        const uint32_t e = e_ahead, toff = toff_ahead;                      // :435-436
-        // :439. The whole entry is subtracted: byte 0 is the length, and only the low six bits of `sft` are ever used (the
-        // 64-bit shift below takes its count modulo 64; 14 <= true sft <= 50) -- a plain v_sub_u32
-        sft -= e;
-        toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
-        if (!ESC_FIRST) e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
+    // The delta a table entry stands for (:435-438): the entry's own value, or -- escape -- the chain's next escape word.
+    auto entry_value = [&](uint32_t e, uint32_t toff) __attribute__((always_inline)) -> uint32_t {
         int32_t val = (int32_t)e >> TE_VALUE_SHIFT;                         // the delta itself (v_ashrrev_i32)
         if (val == TE_SLOW_VALUE) {                                         // escape or wide
             if (!GENERIC) {                                                 // every such entry is an escape whose word is in the pool
@@ -856,7 +850,25 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 asm volatile("; wide table value from global memory %0" : "+v"(val));
             }
         }
-        if (ESC_FIRST) e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
+        return (uint32_t)val;
+    };
+    auto table_entry = [&](uint32_t toff) __attribute__((always_inline)) -> uint32_t {
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff);
+    };
+    // LAYOUT_WORDS: the symbols of a point AND the first symbol of the next one are cut from one 64-bit view, so every
+    // table read hangs on the one before it. esc_first (the third symbol's form): the escape word, if any, is requested
+    // BEFORE the next table entry. LDS results return in issue order, so its value can be waited for (lgkmcnt(1)) while the
+    // look-ahead entry of the next point's first symbol -- needed only at the top of the next iteration -- stays in flight.
+    auto symbol_step = [&](auto esc_first) __attribute__((always_inline)) -> uint32_t {
+        constexpr bool ESC_FIRST = decltype(esc_first)::value;
+        const uint32_t e = e_ahead, toff = toff_ahead;                      // :435-436
+        // :439. The whole entry is subtracted: byte 0 is the length, and only the low six bits of `sft` are ever used (the
+        // 64-bit shift below takes its count modulo 64; 14 <= true sft <= 50) -- a plain v_sub_u32
+        sft -= e;
+        toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
+        if (!ESC_FIRST) e_ahead = table_entry(toff_ahead);
+        const uint32_t val = entry_value(e, toff);
+        if (ESC_FIRST) e_ahead = table_entry(toff_ahead);
 #ifdef PCR_EXP_PAD_VALU   /* experiment: PCR_EXP_PAD_VALU extra independent VALU instructions per symbol step */
         {
             uint32_t pad = tid;
@@ -864,72 +876,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             for (int k = 0; k < PCR_EXP_PAD_VALU; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
         }
 #endif
-        return (uint32_t)val;
-    };
-
-    // first half of rasterize() (:278-287), part 1: the three dot products and the inside test without dividing. For finite
-    // w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1] exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w >
-    // 1 + 2^-24, which rounds above 1); the compare is false for a NaN and for w < 0.
-    auto project_dots = [&]() __attribute__((always_inline)) {
-        qx = __fmaf_rn(m03, 1.0f, __fmaf_rn(m02, fz, __fmaf_rn(m01, fy, m00 * fx)));       // dot4(M + 0, ...)
-        qy = __fmaf_rn(m13, 1.0f, __fmaf_rn(m12, fz, __fmaf_rn(m11, fy, m10 * fx)));       // dot4(M + 4, ...)
-        qw = __fmaf_rn(m33, 1.0f, __fmaf_rn(m32, fz, __fmaf_rn(m31, fy, m30 * fx)));       // dot4(M + 12, ...), operands in VGPRs
-        candidate = fabsf(qx) <= qw && fabsf(qy) <= qw;
-        w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;           // 2^-64 <= w < 2^64
-    };
-    // part 2: the division and the pixel (:279-285). The division is the IEEE sequence hipcc emits for `/` with its range
-    // scaling removed, shared reciprocal, x and y packed; it is bit-identical to `/` for w in [2^-64, 2^64) (no intermediate
-    // leaves the normal range unless |x/w| < 2^-36, where the pixel is the screen centre whatever the last bits are). A
-    // wave in which some candidate's w lies outside that range (or is 0) takes `/` for all lanes.
-    auto project_divide = [&]() __attribute__((always_inline)) {
-        inside = false;
-        if (__builtin_expect(__any(candidate && !w_ok), 0)) {
-            const float nx = qx / qw, ny = qy / qw;
-            if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {   // NaN-rejecting (Appendix C.2)
-                ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);                 // :283-284
-                iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
-                inside = (uint32_t)(ix + iy * img_w) < fb_elems;            // :285
-            }
-        } else if (candidate) {
-            const float r0 = __builtin_amdgcn_rcpf(qw);
-            const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
-            const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
-            const v2f q0 = xy * rr;
-            const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
-            const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
-            const v2f half = {0.5f, 0.5f}, size = {fw, fh};
-            const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
-            ix = (int)img.x; iy = (int)img.y;                                       // :284 (the pixel index is always < fb_elems here)
-            inside = true;
-        }
-    };
-    // part 3: the point becomes the pending one; its framebuffer word is requested now and consumed an iteration later:
-    // from the LDS window if the pixel lies in the batch's rectangle (nearly always), from global memory otherwise (:297)
-    auto project_request = [&]() __attribute__((always_inline)) {
-        bool in_window = false, off_window = false;
-        if (inside) {
-            pend_depth = __float_as_uint(qw);                                       // :287
-            if (MODE == MODE_HQS_COLOR) pend_pix = (uint32_t)(ix + iy * img_w);     // the colour pass names its runs by pixel
-            const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
-            in_window = rx < ww && ry < wh;
-            off_window = !in_window;
-            // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
-            if (MODE == MODE_HQS_COLOR) pend_w = in_window ? ry * ww + rx : 0u; else pend_p = s_win + (in_window ? ry * ww + rx : 0u);
-        }
-        pend_valid = inside;
-        pend_off = off_window;
-        // The window word is read by EVERY lane, wanted or not (a lane that is not inside re-reads its last pixel): with the
-        // read issued on every path hipcc knows how many LDS results are outstanding at the top of the next iteration and
-        // waits for the look-ahead table entry alone (lgkmcnt(1)) instead of for this read as well.
-        // (The global load comes second: a load into the same registers issued behind the LDS read only has to wait for the
-        // LDS counter, the other way round the LDS read would wait for every vector-memory load in flight.)
-        pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
-        if (off_window) {
-            pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
-            // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
-            // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
-            pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
+        return val;
     };
 
     for (int seg = 0; seg < npr_run; seg += 16) {
@@ -942,7 +889,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
           cnext = cblocks[min((seg >> 4) + 1, 3)];
       }
       const int seg_end = min(seg + 16, npr_run);
+#if defined(PCR_EXP_UNROLL) && PCR_EXP_UNROLL == 2
+#pragma unroll 2
+#elif defined(PCR_EXP_UNROLL) && PCR_EXP_UNROLL == 4
+#pragma unroll 4
+#else
 #pragma unroll 1
+#endif
       for (int i = seg; i < seg_end; ++i) {                                 // :428
         uint32_t fetched_hi = 0, fetched_lo = 0;
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {
@@ -957,15 +910,37 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const uint32_t extra1 = lw_load((uint32_t)(i + 8) * LW_ROW_BYTES + tid * 4);
 #endif
 #endif
-        constexpr std::integral_constant<bool, false> table_first{};
-        constexpr std::integral_constant<bool, true> escape_first{};
-        const uint32_t d0 = symbol_step(table_first);                       // :430
-        // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
-        // word has been in flight since the end of the last iteration
-        // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
-        if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
-        const uint32_t d1 = symbol_step(table_first);
-        const uint32_t d2 = symbol_step(escape_first);
+        uint32_t d0, d1, d2;
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) {
+            // The first symbol's key is the top of the point's own window: its entry was requested a whole point ago, and the
+            // one of point i+1 (whose window is already in registers) is requested now. Left on the dependent chain are two LDS
+            // round trips per point: entry 0 -> length -> key 1 -> entry 1 -> length -> key 2 -> entry 2. The second symbol
+            // starts and ends inside the window's first 32 bits (a 32-bit shift: the hardware takes the count modulo 32, and
+            // SFT0 - 32 = 18), the third may reach into the low plane's byte.
+            const uint32_t e0 = e_ahead, toff0 = toff_ahead;
+            toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
+            e_ahead = table_entry(toff_ahead);
+            sft = SFT0 - e0;                                                // :439 (the whole entry: byte 0 is the length)
+            const uint32_t toff1 = ((uint32_t)(bits >> 32) >> (sft & 31u)) & 0x3FFCu;
+            const uint32_t e1 = table_entry(toff1);
+            d0 = entry_value(e0, toff0);                                    // :430
+            // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
+            // word has been in flight since the end of the last iteration
+            // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
+            if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+            sft -= e1;
+            const uint32_t toff2 = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
+            const uint32_t e2 = table_entry(toff2);
+            d1 = entry_value(e1, toff1);
+            d2 = entry_value(e2, toff2);
+        } else {
+            constexpr std::integral_constant<bool, false> table_first{};
+            constexpr std::integral_constant<bool, true> escape_first{};
+            d0 = symbol_step(table_first);                                  // :430
+            if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+            d1 = symbol_step(table_first);
+            d2 = symbol_step(escape_first);
+        }
         if (MODE == MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
@@ -973,9 +948,81 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         PCR_ADVANCE_WORD_WINDOW();
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) g_fb[tid] = 0;
-        if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo; }
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo << 24; }
         continue;
 #endif
+        // (per-point temporaries and the three parts of the projection live inside the loop body: nothing of a point's
+        // projection is carried into the next iteration -- with ix / iy declared outside, every iteration copied them)
+        float fx, fy, fz;
+        float qx, qy, qw;
+        bool candidate, w_ok, inside;
+        int ix, iy;
+        // first half of rasterize() (:278-287), part 1: the three dot products and the inside test without dividing. For finite
+        // w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1] exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w >
+        // 1 + 2^-24, which rounds above 1); the compare is false for a NaN and for w < 0.
+        auto project_dots = [&]() __attribute__((always_inline)) {
+            qx = __fmaf_rn(m03, 1.0f, __fmaf_rn(m02, fz, __fmaf_rn(m01, fy, m00 * fx)));       // dot4(M + 0, ...)
+            qy = __fmaf_rn(m13, 1.0f, __fmaf_rn(m12, fz, __fmaf_rn(m11, fy, m10 * fx)));       // dot4(M + 4, ...)
+            qw = __fmaf_rn(m33, 1.0f, __fmaf_rn(m32, fz, __fmaf_rn(m31, fy, m30 * fx)));       // dot4(M + 12, ...), operands in VGPRs
+            candidate = fabsf(qx) <= qw && fabsf(qy) <= qw;
+            w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;           // 2^-64 <= w < 2^64
+        };
+        // part 2: the division and the pixel (:279-285). The division is the IEEE sequence hipcc emits for `/` with its range
+        // scaling removed, shared reciprocal, x and y packed; it is bit-identical to `/` for w in [2^-64, 2^64) (no intermediate
+        // leaves the normal range unless |x/w| < 2^-36, where the pixel is the screen centre whatever the last bits are). A
+        // wave in which some candidate's w lies outside that range (or is 0) takes `/` for all lanes.
+        auto project_divide = [&]() __attribute__((always_inline)) {
+            // (both forms run for every lane, candidate or not -- a lane that is not one produces a pixel nobody looks at: the
+            // instructions issue for the wave anyway, and with ix / iy written on every path hipcc neither masks the block nor
+            // carries last iteration's pixel along for the lanes that skipped it)
+            if (__builtin_expect(__any(candidate && !w_ok), 0)) {
+                const float nx = qx / qw, ny = qy / qw;
+                ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);                 // :283-284
+                iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+                inside = qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f      // NaN-rejecting (Appendix C.2)
+                         && (uint32_t)(ix + iy * img_w) < fb_elems;         // :285
+            } else {
+                const float r0 = __builtin_amdgcn_rcpf(qw);
+                const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
+                const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
+                const v2f q0 = xy * rr;
+                const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
+                const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
+                const v2f half = {0.5f, 0.5f}, size = {fw, fh};
+                const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
+                ix = (int)img.x; iy = (int)img.y;                                       // :284 (a candidate's pixel index is always < fb_elems here)
+                inside = candidate;
+            }
+        };
+        // part 3: the point becomes the pending one; its framebuffer word is requested now and consumed an iteration later:
+        // from the LDS window if the pixel lies in the batch's rectangle (nearly always), from global memory otherwise (:297)
+        auto project_request = [&]() __attribute__((always_inline)) {
+            bool in_window = false, off_window = false;
+            if (inside) {
+                pend_depth = __float_as_uint(qw);                                       // :287
+                if (MODE == MODE_HQS_COLOR) pend_pix = (uint32_t)(ix + iy * img_w);     // the colour pass names its runs by pixel
+                const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
+                in_window = rx < ww && ry < wh;
+                off_window = !in_window;
+                // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
+                if (MODE == MODE_HQS_COLOR) pend_w = in_window ? ry * ww + rx : 0u; else pend_p = s_win + (in_window ? ry * ww + rx : 0u);
+            }
+            pend_valid = inside;
+            pend_off = off_window;
+            // The window word is read by EVERY lane, wanted or not (a lane that is not inside re-reads its last pixel): with the
+            // read issued on every path hipcc knows how many LDS results are outstanding at the top of the next iteration and
+            // waits for the look-ahead table entry alone (lgkmcnt(1)) instead of for this read as well.
+            // (The global load comes second: a load into the same registers issued behind the LDS read only has to wait for the
+            // LDS counter, the other way round the LDS read would wait for every vector-memory load in flight.)
+            pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
+            if (off_window) {
+                pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
+                // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
+                // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
+                pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        };
+
         if (use_double) {                                                   // :459-461
             fx = (float)__fma_rn((double)px, sx, ox);
             fy = (float)__fma_rn((double)py, sy, oy);
@@ -993,7 +1040,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #else
         project_request();
 #endif
-        if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo; }
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo << 24; }
 #ifdef PCR_EXP_EXTRA_LOAD
         asm volatile("; extra load consumed %0" :: "v"(extra0));
 #if PCR_EXP_EXTRA_LOAD > 1
