@@ -889,13 +889,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
           cnext = cblocks[min((seg >> 4) + 1, 3)];
       }
       const int seg_end = min(seg + 16, npr_run);
-#if defined(PCR_EXP_UNROLL) && PCR_EXP_UNROLL == 2
-#pragma unroll 2
-#elif defined(PCR_EXP_UNROLL) && PCR_EXP_UNROLL == 4
-#pragma unroll 4
-#else
 #pragma unroll 1
-#endif
       for (int i = seg; i < seg_end; ++i) {                                 // :428
         uint32_t fetched_hi = 0, fetched_lo = 0;
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {
