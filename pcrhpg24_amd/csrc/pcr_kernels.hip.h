@@ -630,8 +630,17 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // colour pass layout of the same bytes: sums in the framebuffer's own packed format + the depth to test against
     unsigned long long *const s_rg = s_win, *const s_ba = s_win + win_cap;
     uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * win_cap);
-    // snapshot of the rectangle, K_WIN loads of a thread in flight together (a stale value is a valid start); one round
-    // covers the small configuration's largest window
+    // Basic / depth pass: the window starts EMPTY (all ones) -- what the batch's own points leave in it is merged with one
+    // atomicMin per touched pixel at the end, and min is associative, so the frame is the same as with a snapshot of the
+    // rectangle as the start. (The snapshot let points hidden behind OTHER batches skip their LDS atomic; it cost a global
+    // read of every window pixel in front of the barrier and another one at the merge: 207 MB per 4096x4096 frame.)
+#ifndef PCR_EXP_SNAPSHOT
+    if (MODE != MODE_HQS_COLOR) {
+        for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) s_win[i] = ~0ull;
+    } else
+#endif
+    // colour pass: snapshot of the rectangle's depths, K_WIN loads of a thread in flight together (a stale value is a valid
+    // start); one round covers the small configuration's largest window
     for (uint32_t i0 = 0; i0 < wpix; i0 += WIN_PIXELS_MAX) {                // (uniform)
         constexpr int K_WIN = (WIN_PIXELS_MAX + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE;
         unsigned long long v[K_WIN];
@@ -1063,7 +1072,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             } else {
                 const unsigned long long v = s_win[i];
                 unsigned long long *g = (unsigned long long *)&a.f.fb[gp];
+#ifndef PCR_EXP_SNAPSHOT
+                if (v != ~0ull && v < *g) atomicMin(g, v);                  // (a pixel no point of the batch reached is not even read)
+#else
                 if (v < *g) atomicMin(g, v);
+#endif
             }
         }
     }
