@@ -43,7 +43,8 @@ struct pcr_ctx {
     int32_t *d_cluster_sizes = nullptr;
     uint8_t *d_colors = nullptr;
     uint32_t *d_lod = nullptr;
-    uint2 *d_win = nullptr;
+    WinPlan *d_win = nullptr;                   // LDS framebuffer windows of the frame's batches (prepass)
+    uint32_t *d_batch_runs = nullptr;           // runs of chains and their bounding boxes, RUN_WORDS per batch (k_bounds)
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
     // dense lists of the batches a frame draws, compacted by k_lod_prepass per workgroup (see RenderArgs): d_order[2][order_stride],
     // d_chunk_count[2][PCR_MAX_PREPASS_WORKGROUPS]
@@ -166,7 +167,7 @@ void free_stream_buffers(pcr_ctx *c)
     c->batches_resident = 0;
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
-    dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); c->transcoded = 0;
+    dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); dfree(c->d_batch_runs); c->transcoded = 0;
     dfree(c->d_order); dfree(c->d_chunk_count); dfree(c->d_any_generic); c->order_stride = 0;
     if (c->any_generic_pending && c->any_generic_ev) (void)hipEventSynchronize(c->any_generic_ev);
     c->any_generic_pending = false;
@@ -225,7 +226,7 @@ StreamView make_stream_view(pcr_ctx *c)
     s.separate = c->d_separate; s.separate_sizes = c->d_sep_sizes; s.table_values = c->d_table_values;
     s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors;
     s.lane_words = c->d_lane_words; s.batch_flags = c->d_batch_flags; s.packed_table = c->d_packed_table;
-    s.point_windows = c->d_point_windows;
+    s.point_windows = c->d_point_windows; s.batch_runs = c->d_batch_runs;
     s.encoded_words = c->enc_words; s.separate_words = c->sep_words;
     s.num_batches = c->visible_batches(); s.batch_index_base = c->batch_index_base;
     return s;
@@ -267,6 +268,8 @@ void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
             hipLaunchKernelGGL(k_transcode, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
                                make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows,
                                c->d_any_generic, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
+            hipLaunchKernelGGL(k_bounds, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
+                               make_stream_view(c), c->d_lane_words, c->d_batch_runs, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
             b0 += n;
         }
         c->transcoded = std::max(c->transcoded, final_end);
@@ -384,7 +387,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r02.v58"; }
+const char *pcr_kernel_version(void) { return "r02.v62"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -495,6 +498,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_win, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_lane_words, lw_batches * LW_ROWS * PCR_WORKGROUP_SIZE, acc)) || (rc = dalloc_zero(c, c->d_batch_flags, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
+        (rc = dalloc_zero(c, c->d_batch_runs, nB * RUN_WORDS, acc)) ||
         (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES, acc)) ||
         (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
         (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc)))) {

@@ -112,6 +112,7 @@ struct StreamView {
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
     const uint8_t  *point_windows;    // [nB * PW_BATCH_BYTES + PW_GUARD_BYTES] or NULL (layout), written by k_transcode
+    const uint32_t *batch_runs;       // [nB * RUN_WORDS] k_bounds: where a batch's chains fall apart into spatial clusters (see BatchRuns)
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
@@ -125,12 +126,29 @@ struct FrameView {
     uint32_t  fb_elems;
 };
 
+// A batch's points are 65 536 consecutive points of the Morton order, chain t = points 64 t .. 64 t + 63. Where the curve
+// jumps, the batch is two (or more) compact clusters far apart: at 1080p 25 of the benchmark's 1526 batches have bounding
+// rectangles of up to 600 x 80 pixels for a few hundred touched ones, which no LDS window holds. Those batches took ~4x as
+// long as the others -- their points went through global pre-reads and atomics -- and, being stragglers, cost the launch 9 %
+// (4096x4096: a fifth of the batches, 38 %). So, once per loaded batch (k_bounds, camera independent): the three largest gaps
+// between consecutive chains cut the batch into RUNS runs of chains, each with its own bounding box.
+constexpr int RUNS = 4;
+constexpr int RUN_WORDS = 4 + RUNS * 6;     // {first chain of run 1, 2, 3, 0} then per run {min xyz, max xyz} as floats
+// Per frame (prepass, a placement hint: any plan gives the same frame): one LDS framebuffer window per run, or one for the
+// whole batch when the runs' rectangles overlap anyway. first[r] = first chain of run r + 1 (1024: no such run); window r
+// sits behind windows 0 .. r-1 in the array of window pixels.
+struct WinPlan {
+    uint32_t xy[RUNS], wh[RUNS];      // {x0 | y0<<16}, {w | h<<16}; w == 0: none
+    uint32_t first[RUNS - 1];
+    uint32_t reserved;
+};
+
 struct RenderArgs {
     pcr_render_params p;
     StreamView s;
     FrameView f;
     uint32_t *lod;            // [nB]
-    uint2 *win;               // [nB] LDS depth-window rectangle per batch: {x0 | y0<<16, w | h<<16}, w == 0: none
+    WinPlan *win;             // [nB] LDS framebuffer windows per batch
     pcr_render_stats *stats;  // device: one partial record per prepass workgroup
     // Dense lists of the batches k_render has to draw (frustum-culled batches and batches whose level of detail is zero
     // points are left out), compacted by the prepass in two levels that keep the file's (Morton) order: every prepass
@@ -197,6 +215,7 @@ __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_r
 constexpr int PREPASS_LANES = 8;
 constexpr int PREPASS_BATCHES = PREPASS_THREADS / PREPASS_LANES;     // batches per workgroup
 __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
+__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int j);
 
 __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t block)
 {
@@ -228,6 +247,123 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
                     block * PREPASS_BATCHES + threadIdx.x;
         }
     }
+    // LDS framebuffer windows of the batches that draw: RUNS lanes per batch, one per run of chains
+    static_assert(PREPASS_BATCHES * RUNS <= PREPASS_THREADS, "one round");
+    if (threadIdx.x < PREPASS_BATCHES * RUNS) {
+        const uint32_t slot = threadIdx.x / RUNS;
+        const int64_t b = (int64_t)block * PREPASS_BATCHES + slot;
+        if (b < a.s.num_batches && s_kind[slot]) plan_windows(a, b, (int)(threadIdx.x % RUNS));     // (uniform per RUNS lanes)
+    }
+}
+
+// One lane per run: the screen rectangle of the run's bounding box (k_bounds), then LDS pixels for the RUNS rectangles. Only a
+// placement hint -- points that land outside their window take the global path -- so nothing here needs exactness, only
+// rectangles inside the image and a pixel count within the LDS.
+struct IRect { int x0, y0, x1, y1; };
+__device__ __forceinline__ int rect_area(IRect r) { return r.x1 >= r.x0 && r.y1 >= r.y0 ? (r.x1 - r.x0 + 1) * (r.y1 - r.y0 + 1) : 0; }
+// the central part of a rectangle, scaled by sc < 1 per side (what is outside goes the global way)
+__device__ __forceinline__ IRect rect_shrink(IRect r, float sc)
+{
+    const int w = r.x1 - r.x0 + 1, h = r.y1 - r.y0 + 1;
+    if (w <= 0 || h <= 0) return r;
+    const int nw = max(1, (int)floorf((float)w * sc)), nh = max(1, (int)floorf((float)h * sc));
+    const int x0 = r.x0 + (w - nw) / 2, y0 = r.y0 + (h - nh) / 2;
+    return { x0, y0, x0 + nw - 1, y0 + nh - 1 };
+}
+__device__ __forceinline__ void rect_pack(IRect r, uint32_t &xy, uint32_t &wh)
+{
+    if (r.x1 < r.x0 || r.y1 < r.y0 || r.x0 < 0 || r.y0 < 0 || r.x0 >= 65536 || r.y0 >= 65536) { xy = 0; wh = 0; return; }
+    xy = (uint32_t)r.x0 | ((uint32_t)r.y0 << 16);
+    wh = (uint32_t)(r.x1 - r.x0 + 1) | ((uint32_t)(r.y1 - r.y0 + 1) << 16);
+}
+
+__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int r)
+{
+    const pcr_render_params &p = a.p;
+    const float fw = (float)p.width, fh = (float)p.height;
+    const int cap = window_capacity((uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023], a.win_pixel_bytes, a.dyn_lds_bytes);
+    const uint32_t *runs = a.s.batch_runs + (size_t)b * RUN_WORDS;
+    const float *box = reinterpret_cast<const float *>(runs + 4 + r * 6);
+    const float bmin[3] = { box[0], box[1], box[2] }, bmax[3] = { box[3], box[4], box[5] };
+    const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };      // identity of the union
+    IRect mine = none;
+    {
+        bool front = true;
+        float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
+            const float w = dot4(p.transform + 12, x, y, z, 1.0f);
+            front = front && w > 1.0e-6f;
+            const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
+            const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
+            minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+        }
+        // (a box that reaches behind the camera, holds a NaN, or lies off screen gets no rectangle: its points take the global path)
+        if (front && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
+            mine.x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1); mine.x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
+            mine.y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1); mine.y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
+            if (mine.x1 < mine.x0 || mine.y1 < mine.y0) mine = none;
+        }
+    }
+    auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
+    auto group_max = [](int v) { v = max(v, __shfl_xor(v, 1, RUNS)); v = max(v, __shfl_xor(v, 2, RUNS)); return v; };
+    int sum = group_sum(rect_area(mine));
+    WinPlan *out = a.win + b;
+    // The rectangle of the batch's own bounding box (GPUBatch: it holds every point, the runs' boxes leave the straddling chains
+    // out): if the LDS holds it, it is the one window of the batch and no point lands outside.
+    IRect whole = none;
+    {
+        const pcr_gpu_batch *g = a.s.batches + b;
+        const float lm[3] = { (float)g->las_min_x, (float)g->las_min_y, (float)g->las_min_z };
+        const float gmin[3] = { g->min_x - lm[0], g->min_y - lm[1], g->min_z - lm[2] }, gmax[3] = { g->max_x - lm[0], g->max_y - lm[1], g->max_z - lm[2] };
+        // corners 2 r and 2 r + 1 per lane, then the union over the group
+        bool front = true;
+        float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
+#pragma unroll
+        for (int c2 = 0; c2 < 8 / RUNS; ++c2) {
+            const int c = r * (8 / RUNS) + c2;
+            const float x = (c & 1) ? gmax[0] : gmin[0], y = (c & 2) ? gmax[1] : gmin[1], z = (c & 4) ? gmax[2] : gmin[2];
+            const float w = dot4(p.transform + 12, x, y, z, 1.0f);
+            front = front && w > 1.0e-6f;
+            const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
+            const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
+            minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+        }
+#pragma unroll
+        for (int m = 1; m < RUNS; m <<= 1) {
+            minx = fminf(minx, __shfl_xor(minx, m, RUNS)); maxx = fmaxf(maxx, __shfl_xor(maxx, m, RUNS));
+            miny = fminf(miny, __shfl_xor(miny, m, RUNS)); maxy = fmaxf(maxy, __shfl_xor(maxy, m, RUNS));
+        }
+        const bool all_front = (group_sum(front ? 1 : 0) == RUNS);
+        if (all_front && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
+            whole.x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1); whole.x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
+            whole.y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1); whole.y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
+        }
+    }
+    if (rect_area(whole) > 0 && rect_area(whole) <= cap) {
+        uint32_t xy = 0, wh = 0;
+        if (r == 0) rect_pack(whole, xy, wh);
+        out->xy[r] = xy; out->wh[r] = wh;                                           // (runs 1..3: no window of their own)
+        if (r < RUNS - 1) out->first[r] = PCR_WORKGROUP_SIZE;                       // every chain belongs to run 0
+        if (r == 0) out->reserved = 0;
+        return;
+    }
+    // one window per run; while they do not fit together, the largest gives way (a run with a jump of its own inside)
+#pragma unroll 1
+    for (int round = 0; round < 6 && sum > cap; ++round) {
+        const int area = rect_area(mine), largest = group_max(area);
+        // (ties: every holder of the largest area shrinks -- the loop ends all the same)
+        if (area == largest) {
+            const int target = max(largest - (sum - cap), largest / 4);
+            mine = target >= 1 ? rect_shrink(mine, sqrtf((float)target / (float)largest)) : none;
+        }
+        sum = group_sum(rect_area(mine));
+    }
+    if (sum > cap) mine = none;                                                     // hopeless: this run goes the global way
+    rect_pack(mine, out->xy[r], out->wh[r]);
+    if (r < RUNS - 1) out->first[r] = min(runs[r], (uint32_t)PCR_WORKGROUP_SIZE);
+    if (r == 0) out->reserved = 0;
 }
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
@@ -241,7 +377,7 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
     const float bmin[3] = { g.min_x - lm[0], g.min_y - lm[1], g.min_z - lm[2] };             // :340
     const float bmax[3] = { g.max_x - lm[0], g.max_y - lm[1], g.max_z - lm[2] };             // :341
 
-    if (lane == 0) st.batches_total += 1;
+    if (lane == 0) st.batches_total = 1;
     if (p.enable_frustum_culling) {                                                          // :342-344
         // planes (3-0), (3+0), (3+1), (3-1), (3-2), (3+2) of the transposed matrix (three.js convention, :246-259);
         // x + s*y with s = +-1 is the same rounding as x +- y
@@ -254,7 +390,8 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
                                    M[15] + sgn * M[4 * r + 3], bmin, bmax);
         const uint32_t votes = (uint32_t)(__ballot(accept) >> group_shift) & 0xFFu;
         if (votes != 0xFFu) {
-            if (lane == 0) { a.lod[b] = LOD_CULLED; st.batches_culled += 1; }
+            if (lane == 0) { a.lod[b] = LOD_CULLED; st.batches_culled = 1; }      // (plain stores to distinct fields: with `+=` hipcc
+                                                                                      // merged them into one store at a computed offset -- scratch)
             return;
         }
     }
@@ -284,43 +421,10 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
     npr = max(npr, 0);
     if (lane == 0) {
         a.lod[b] = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
-        st.points_iterated += (int64_t)npr * PCR_WORKGROUP_SIZE;
-        if (use_double) st.batches_double += 1;
+        st.points_iterated = (int64_t)npr * PCR_WORKGROUP_SIZE;
+        st.batches_double = use_double ? 1 : 0;
     }
 
-    // Screen rectangle of the batch's bounding box: where k_render keeps its LDS copy of the framebuffer. This is
-    // only a cache placement hint (points that land outside it take the global path), so it needs no exactness.
-    uint2 wr = make_uint2(0, 0);
-    const int win_capacity = window_capacity((uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023], a.win_pixel_bytes, a.dyn_lds_bytes);
-    {
-        // corner `lane` of the box, then min / max over the group's eight lanes
-        const int c = lane;
-        const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
-        const float w = dot4(p.transform + 12, x, y, z, 1.0f);
-        const bool front = w > 1.0e-6f;
-        const bool ok = ((uint32_t)(__ballot(front) >> group_shift) & 0xFFu) == 0xFFu;
-        float minx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw, maxx = minx;
-        float miny = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh, maxy = miny;
-#pragma unroll
-        for (int m = 1; m < PREPASS_LANES; m <<= 1) {
-            minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
-            miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
-        }
-        if (ok && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
-            int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
-            int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
-            int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
-            if (ww > 0 && wh > 0 && (int64_t)ww * wh > win_capacity && (int64_t)ww * wh <= 16 * (int64_t)win_capacity) {
-                // too large for LDS: keep the central part of the rectangle (same aspect); the rest goes the global way
-                const float sc = sqrtf((float)win_capacity / ((float)ww * (float)wh));
-                const int nw = max(1, (int)floorf((float)ww * sc)), nh = max(1, (int)floorf((float)wh * sc));
-                x0 += (ww - nw) / 2; y0 += (wh - nh) / 2; ww = nw; wh = nh;
-            }
-            if (ww > 0 && wh > 0 && ww * wh <= win_capacity && x0 < 65536 && y0 < 65536)
-                wr = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)ww | ((uint32_t)wh << 16));
-        }
-    }
-    if (lane == 0) a.win[b] = wr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,6 +625,146 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_bounds: once per loaded batch, behind k_transcode (same launch geometry, same chunk of batches): where the batch's chains
+// fall apart into spatial clusters (BatchRuns above). Every lane decodes its chain (the plain checked form of the decode, from
+// the chain's own word sequence) and takes the bounding box of its 64 points; the three largest jumps between the box centres
+// of consecutive chains cut the batch into four runs; each run gets the box of its chains. A hint and nothing more: it is
+// computed with the float form of the dequantisation only (the double form of :459-461 differs by an ulp) and includes
+// whatever the chains' garbage tails decode to -- and a frame is the same whatever the windows are.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_order(float f) { const uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float float_unorder(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_bounds(StreamView s, const uint32_t *lane_words, uint32_t *batch_runs,
+                                                               int first_batch, int lane_words_first)
+{
+    const uint32_t b = (uint32_t)first_batch + blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    __shared__ __align__(16) uint32_t s_table[PCR_HUFFMAN_TABLE_SIZE];
+    __shared__ float s_centre[PCR_WORKGROUP_SIZE][3];
+    __shared__ uint8_t s_outlier[PCR_WORKGROUP_SIZE];
+    __shared__ float s_mean[PCR_WORKGROUP_SIZE / 64];
+    __shared__ unsigned long long s_best[PCR_WORKGROUP_SIZE / 64];
+    __shared__ uint32_t s_cut[RUNS - 1];
+    __shared__ uint32_t s_box[RUNS][6];
+    reinterpret_cast<uint4 *>(s_table)[tid] = reinterpret_cast<const uint4 *>(s.packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+    if (tid < RUNS * 6) s_box[tid / 6][tid % 6] = (tid % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    const pcr_gpu_batch *gb = s.batches + b;
+    const int32_t *sep = s.separate + gb->separate_batch_offset;
+    const uint32_t sep_last = (uint32_t)min((int64_t)0x7FFFFFF0, s.separate_words + (PCR_GUARD_WORDS - 2) - gb->separate_batch_offset);
+    const int32_t *tvalues = s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE;
+    uint32_t esc = tid ? (uint32_t)s.separate_sizes[(size_t)b * 1024 + tid - 1] : 0u;
+    const uint32_t *col = lane_words + (size_t)(b - (uint32_t)lane_words_first) * LW_ROWS * PCR_WORKGROUP_SIZE + tid;
+    const int32_t *sv = s.start_values + ((size_t)b * 1024 + tid) * 3;
+    int32_t pos[3] = { sv[0], sv[1], sv[2] };
+    const float fs[3] = { (float)gb->scale_x, (float)gb->scale_y, (float)gb->scale_z };
+    const float fo[3] = { (float)(gb->offset_x - gb->las_min_x), (float)(gb->offset_y - gb->las_min_y), (float)(gb->offset_z - gb->las_min_z) };
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    __syncthreads();
+    // the chain's bit stream = its words in order; `buf` holds the next `avail` (> 32) unconsumed bits at its top
+    uint64_t buf = ((uint64_t)col[0] << 32) | col[PCR_WORKGROUP_SIZE];
+    uint32_t row = 2;
+    int avail = 64;
+#pragma unroll 1
+    for (int i = 0; i < PCR_POINTS_PER_THREAD; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t key = (uint32_t)(buf >> 52);
+            const uint32_t e = s_table[key];
+            int32_t val = (int32_t)e >> TE_VALUE_SHIFT;
+            if (val == TE_SLOW_VALUE) {
+                if (e & TE_ESCAPE) val = sep[min(esc++, sep_last)];
+                else               val = tvalues[key];
+            }
+            pos[k] = (int32_t)((uint32_t)pos[k] + (uint32_t)val);
+            const int len = (int)(e & 63u);                 // (a malformed table's longer "lengths" only make the hint useless)
+            buf <<= len; avail -= len;
+            if (avail <= 32) {
+                const uint32_t w = row < (uint32_t)LW_ROWS ? col[(size_t)row * PCR_WORKGROUP_SIZE] : 0u;
+                ++row;
+                buf |= (uint64_t)w << ((32 - avail) & 63);
+                avail += 32;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float f = __fmaf_rn((float)pos[k], fs[k], fo[k]);
+            mn[k] = fminf(mn[k], f); mx[k] = fmaxf(mx[k], f);
+        }
+    }
+    // A chain whose own 64 points straddle a jump of the curve (or whose garbage tail flew off) has a box far larger than its
+    // neighbours': it would give a jump on either side and then blow up the box of the run it ends up in. Such chains -- extent
+    // over four times the batch's mean -- are looked through when jumps are measured and left out of the runs' boxes (their few
+    // points go the global way).
+    float extent = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) extent = fmaxf(extent, mx[k] - mn[k]);
+    if (!(extent >= 0.0f)) extent = 3.0e38f;                // (NaN)
+    {
+        float sum = fminf(extent, 1.0e30f);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+        if ((tid & 63u) == 0) s_mean[tid >> 6] = sum;
+    }
+    __syncthreads();
+    float mean = 0.0f;
+#pragma unroll
+    for (int w = 0; w < PCR_WORKGROUP_SIZE / 64; ++w) mean += s_mean[w];
+    mean *= 1.0f / (float)PCR_WORKGROUP_SIZE;
+    const bool outlier = extent > 4.0f * mean;
+    // jump between my chain's box centre and the one of the nearest ordinary chain before it (at most four back)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_centre[tid][k] = 0.5f * mn[k] + 0.5f * mx[k];
+    s_outlier[tid] = outlier ? 1 : 0;
+    __syncthreads();
+    float gap = -1.0f;
+    if (tid && !outlier) {
+        uint32_t prev = tid - 1;
+#pragma unroll
+        for (int back = 0; back < 3; ++back) if (prev && s_outlier[prev]) --prev;
+        gap = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gap = fmaxf(gap, fabsf(s_centre[tid][k] - s_centre[prev][k]));
+        if (!(gap >= 0.0f) || s_outlier[prev]) gap = 0.0f;
+    }
+    // the RUNS - 1 largest jumps, one after the other: wave maximum of (gap, chain) by shuffles, then over the 16 waves
+    for (int round = 0; round < RUNS - 1; ++round) {
+        unsigned long long key = gap >= 0.0f ? ((unsigned long long)__float_as_uint(gap) << 32) | tid : 0ull;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, m);
+            key = key > o ? key : o;
+        }
+        if ((tid & 63u) == 0) s_best[tid >> 6] = key;
+        __syncthreads();
+        unsigned long long best = s_best[0];
+#pragma unroll
+        for (int w = 1; w < PCR_WORKGROUP_SIZE / 64; ++w) best = best > s_best[w] ? best : s_best[w];
+        const uint32_t cut = (uint32_t)best;                // (0 if there is no chain left to cut at: a run of no chains)
+        if (tid == cut) gap = -1.0f;
+        if (tid == 0) s_cut[round] = cut ? cut : (uint32_t)PCR_WORKGROUP_SIZE;
+        __syncthreads();
+    }
+    uint32_t c0 = s_cut[0], c1 = s_cut[1], c2 = s_cut[2];
+    static_assert(RUNS == 4, "three cuts, sorted by hand");
+    if (c0 > c1) { const uint32_t t = c0; c0 = c1; c1 = t; }
+    if (c1 > c2) { const uint32_t t = c1; c1 = c2; c2 = t; }
+    if (c0 > c1) { const uint32_t t = c0; c0 = c1; c1 = t; }
+    const uint32_t run = (tid >= c0) + (tid >= c1) + (tid >= c2);
+    if (!outlier) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&s_box[run][k], float_order(mn[k]));
+            atomicMax(&s_box[run][3 + k], float_order(mx[k]));
+        }
+    }
+    __syncthreads();
+    uint32_t *out = batch_runs + (size_t)b * RUN_WORDS;
+    if (tid < 4) out[tid] = tid == 0 ? c0 : tid == 1 ? c1 : tid == 2 ? c2 : 0u;
+    if (tid < RUNS * 6) out[4 + tid] = __float_as_uint(float_unorder(s_box[tid / 6][tid % 6]));
+}
+
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -622,43 +866,49 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const int32_t *esc_next = s_esc + (tid ? (uint32_t)ssz[tid - 1] : 0u);
 
     // ---- framebuffer window of the batch's rectangle -> LDS --------------------------------------------------
-    const uint2 wr = a.win[b];
-    const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
-    const uint32_t wpix = ww * wh;                          // 0: no window for this batch
+    // Up to RUNS rectangles per batch (WinPlan): my chain scatters into the window of its run; all of them live in one array of
+    // window pixels, in run order. The window is a per-lane matter (runs do not end at wave boundaries): its origin, size and
+    // first pixel sit in vector registers.
+    const WinPlan *const plan_p = a.win + b;                // (read field by field: a local copy indexed in a loop lands in scratch)
+    uint32_t wpix = 0;                                      // pixels of all windows together; 0: no window for this batch
+    uint32_t wx0 = 0, wy0 = 0, ww = 0, wh = 0, wbase = 0;
+    {
+        const uint32_t run = (tid >= plan_p->first[0]) + (tid >= plan_p->first[1]) + (tid >= plan_p->first[2]);
+        static_assert(RUNS == 4, "three run boundaries");
+#pragma unroll
+        for (int r = 0; r < RUNS; ++r) {
+            const uint32_t xy = plan_p->xy[r], wh2 = plan_p->wh[r];
+            if (run == (uint32_t)r) { wx0 = xy & 0xFFFFu; wy0 = xy >> 16; ww = wh2 & 0xFFFFu; wh = wh2 >> 16; wbase = wpix; }
+            wpix += (wh2 & 0xFFFFu) * (wh2 >> 16);
+        }
+    }
     const uint32_t W = (uint32_t)a.p.width;
-    const float inv_ww = 1.0f / (float)max(ww, 1u);
     // colour pass layout of the same bytes: sums in the framebuffer's own packed format + the depth to test against
     unsigned long long *const s_rg = s_win, *const s_ba = s_win + win_cap;
     uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * win_cap);
-    // Basic / depth pass: the window starts EMPTY (all ones) -- what the batch's own points leave in it is merged with one
-    // atomicMin per touched pixel at the end, and min is associative, so the frame is the same as with a snapshot of the
-    // rectangle as the start. (The snapshot let points hidden behind OTHER batches skip their LDS atomic; it cost a global
-    // read of every window pixel in front of the barrier and another one at the merge: 207 MB per 4096x4096 frame.)
-#ifndef PCR_EXP_SNAPSHOT
+    // every pixel of every window in turn: fn(index in the window arrays, index in the framebuffer)
+    auto for_window_pixels = [&](auto fn) __attribute__((always_inline)) {
+        uint32_t base = 0;
+#pragma unroll 1
+        for (int r = 0; r < RUNS; ++r) {                                    // (uniform)
+            const uint32_t xy = plan_p->xy[r], wh2 = plan_p->wh[r];
+            const uint32_t x0 = xy & 0xFFFFu, y0 = xy >> 16, w2 = wh2 & 0xFFFFu, n = w2 * (wh2 >> 16);
+            const float inv_w2 = 1.0f / (float)max(w2, 1u);
+            for (uint32_t i = tid; i < n; i += PCR_WORKGROUP_SIZE) {         // (n == 0: no such window)
+                uint32_t y, x;
+                window_row_col(i, w2, inv_w2, y, x);
+                fn(base + i, (size_t)(y0 + y) * W + x0 + x);
+            }
+            base += n;
+        }
+    };
     if (MODE != MODE_HQS_COLOR) {
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) s_win[i] = ~0ull;
-    } else
-#endif
-    // colour pass: snapshot of the rectangle's depths, K_WIN loads of a thread in flight together (a stale value is a valid
-    // start); one round covers the small configuration's largest window
-    for (uint32_t i0 = 0; i0 < wpix; i0 += WIN_PIXELS_MAX) {                // (uniform)
-        constexpr int K_WIN = (WIN_PIXELS_MAX + PCR_WORKGROUP_SIZE - 1) / PCR_WORKGROUP_SIZE;
-        unsigned long long v[K_WIN];
-#pragma unroll
-        for (int k = 0; k < K_WIN; ++k) {
-            const uint32_t i = i0 + tid + k * PCR_WORKGROUP_SIZE;
-            uint32_t y, x;
-            window_row_col(i, ww, inv_ww, y, x);
-            v[k] = i < wpix ? a.f.fb[(size_t)(wy0 + y) * W + wx0 + x] : 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < K_WIN; ++k) {
-            const uint32_t i = i0 + tid + k * PCR_WORKGROUP_SIZE;
-            if (i < wpix && tid + k * PCR_WORKGROUP_SIZE < WIN_PIXELS_MAX) {
-                if (MODE == MODE_HQS_COLOR) { s_depth[i] = (uint32_t)(v[k] >> 32); s_rg[i] = 0; s_ba[i] = 0; }
-                else                        s_win[i] = v[k];
-            }
-        }
+    } else {
+        // colour pass: the depths of the rectangles as the depth pass left them, sums zeroed
+        for_window_pixels([&](uint32_t i, size_t gp) {
+            s_depth[i] = (uint32_t)(a.f.fb[gp] >> 32); s_rg[i] = 0; s_ba[i] = 0;
+        });
     }
 
     // ---- my chain's own word sequence (k_transcode) ---------------------------------------------------------
@@ -799,6 +1049,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     bool pend_valid = false, pend_off = false;
     uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
+    unsigned long long *const s_win_mine = s_win + wbase;   // my wave's window
     unsigned long long *pend_p = s_win;                     // basic / depth pass: the pending point's word in the LDS window
     uint64_t pend_old = 0;
 
@@ -813,7 +1064,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     auto in_vgpr_f = [](float v) { if (!VGPR_CONSTANTS) return v; float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     auto in_vgpr_u = [](uint32_t v) { if (!VGPR_CONSTANTS) return v; uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     const float m30 = in_vgpr_f(M[12]), m31 = in_vgpr_f(M[13]), m32 = in_vgpr_f(M[14]), m33 = in_vgpr_f(M[15]);   // the w row
-    const uint32_t v_wx0 = in_vgpr_u(wx0), v_wy0 = in_vgpr_u(wy0);
+    const uint32_t v_wx0 = wx0, v_wy0 = wy0;                // (per-lane values: in vector registers anyway)
 
     __syncthreads();        // table, escapes and window are visible
 
@@ -1008,7 +1259,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 in_window = rx < ww && ry < wh;
                 off_window = !in_window;
                 // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
-                if (MODE == MODE_HQS_COLOR) pend_w = in_window ? ry * ww + rx : 0u; else pend_p = s_win + (in_window ? ry * ww + rx : 0u);
+                if (MODE == MODE_HQS_COLOR) pend_w = wbase + (in_window ? ry * ww + rx : 0u); else pend_p = s_win_mine + (in_window ? ry * ww + rx : 0u);
             }
             pend_valid = inside;
             pend_off = off_window;
@@ -1059,10 +1310,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
     if (wpix) {
         __syncthreads();
-        for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
-            uint32_t y, x;
-            window_row_col(i, ww, inv_ww, y, x);
-            const size_t gp = (size_t)(wy0 + y) * W + wx0 + x;
+        for_window_pixels([&](uint32_t i, size_t gp) {
             if (MODE == MODE_HQS_COLOR) {
                 const unsigned long long vba = s_ba[i];
                 if (vba) {
@@ -1072,13 +1320,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             } else {
                 const unsigned long long v = s_win[i];
                 unsigned long long *g = (unsigned long long *)&a.f.fb[gp];
-#ifndef PCR_EXP_SNAPSHOT
                 if (v != ~0ull && v < *g) atomicMin(g, v);                  // (a pixel no point of the batch reached is not even read)
-#else
-                if (v < *g) atomicMin(g, v);
-#endif
             }
-        }
+        });
     }
 }
 
