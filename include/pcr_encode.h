@@ -56,6 +56,9 @@ void pcr_host_free(void *p);
  * default (flag clear) reproduces the reference's stream byte for byte, quirk included. */
 #define PCR_ENCODE_MORTON_SORT 1
 #define PCR_ENCODE_PAD_TAILS   2
+/* colours as BC7 mode-6 blocks (16 B per 16 points) instead of BC1: the file a reference built with COLOR_COMPRESSION == 7
+ * writes and reads (src/preprocess.cpp:299-316, :1129-1138). Only the HQS method draws such a stream (include/pcr_hip.h). */
+#define PCR_ENCODE_BC7         4
 
 /* Encode n points (int32 LAS coordinates + 0x00BBGGRR colours) into a complete .huffman file image.
  * Points are processed in chunks of chunk_points (<=0: default); each chunk is padded, optionally
@@ -98,6 +101,8 @@ int pcr_table_from_dict(const int32_t *dict_symbols, const uint32_t *dict_cw, co
                         int64_t dict_n, int32_t *dt_values, int32_t *dt_cwlen);
 /* BC1-encode 16 colours (0x00BBGGRR) into 8 bytes, 4-colour mode only. */
 void pcr_bc1_encode_block(const uint32_t *colors16, uint8_t *out8);
+/* BC7 mode-6 encode 16 colours into 16 bytes (alpha 255). */
+void pcr_bc7_encode_block(const uint32_t *colors16, uint8_t *out16);
 
 /* 10-10-10 three-level quantisation of the `loop_las_cuda` method: what the reference's loader shader produces
  * (modules/compute/computeLasLoader.cs:147-190 getPoint, 193-252 computeBoundingBox, 255-357 processPoints), for

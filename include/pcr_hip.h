@@ -184,6 +184,13 @@ int pcr_set_render_variant(pcr_ctx *ctx, int variant);
 /* Device bytes the loaded stream occupies right now (every per-stream allocation of the context, pads and guards included;
  * framebuffers excluded). Drops when the first frame after the last upload releases what only the load-time transcode reads. */
 int64_t pcr_stream_resident_bytes(const pcr_ctx *ctx);
+/* Colour format of the loaded stream: PCR_COLOR_BC1, PCR_COLOR_BC7 (a file written by a reference built with
+ * COLOR_COMPRESSION == 7, include/BatchDumpData.h:130-136: 16 colour bytes per 16 points; told by the size of the first
+ * record uploaded), 0 before the first record. A BC7 stream is drawn by the HQS method only (pcr_render_hqs_color decodes
+ * mode-6 blocks as huffman_hqs/render.cu:240-273 does); pcr_render_basic refuses it: the reference's basic method decodes
+ * the array as BC1 whatever the setting (huffman_mem_iter_cuda/render.cu:299) and its resolve then indexes it with a colour
+ * (resolve.cu:183), which is not a result to be identical to. */
+int pcr_stream_color_format(const pcr_ctx *ctx);
 /* Version tag of the render/transcode kernels in this library ("rNN.vMM"): stored measurements name the tag they belong to. */
 const char *pcr_kernel_version(void);
 

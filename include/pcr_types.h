@@ -33,6 +33,10 @@ extern "C" {
 #define PCR_CLUSTER_LANES         32     /* the stream is interleaved for 32-lane clusters (src/preprocess.cpp:540-587) */
 #define PCR_CLUSTERS_PER_BATCH    (PCR_WORKGROUP_SIZE / PCR_CLUSTER_LANES)     /* 32 */
 #define PCR_COLOR_BYTES_PER_BATCH (PCR_POINTS_PER_BATCH / 2)                   /* BC1: 8 B per 16 points */
+#define PCR_COLOR_BYTES_PER_BATCH_BC7 PCR_POINTS_PER_BATCH                     /* BC7 mode 6: 16 B per 16 points (COLOR_COMPRESSION == 7) */
+/* colour format of a stream (the reference's compile-time COLOR_COMPRESSION, BatchDumpData.h:130-136): told by the size of its records */
+#define PCR_COLOR_BC1 1
+#define PCR_COLOR_BC7 7
 #define PCR_BATCH_FIXED_HEADER    124    /* bytes before start_values in a batch record (include/BatchDumpData.h:60-107) */
 
 /* Zero padding (in 32-bit words) kept behind the encoded / escape streams so the reference's tail

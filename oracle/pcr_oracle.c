@@ -140,6 +140,36 @@ uint32_t pcr_oracle_decode_bc1(uint64_t point_index, const uint8_t *colors)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * BC7 mode-6 colour as the reference's kernels decode it (COLOR_COMPRESSION == 7): huffman_hqs/render.cu:240-273 (the same
+ * function in huffman_mem_iter_cuda/render.cu:121-154 and resolve.cu:115). struct bc7_mode_6 (render.cu:66-110): low
+ * quadword = mode:7 r0:7 r1:7 g0:7 g1:7 b0:7 b1:7 a0:7 a1:7 p0:1, high quadword = p1:1 then the sixteen indices, 3 bits for
+ * pixel 0 and 4 for the others. Endpoint = (7 bits << 1) | p-bit. The kernel takes `(hi >> (4 * local)) & 15` as the index of
+ * EVERY pixel, so pixels 1..15 get their BC7 index and pixel 0 gets (index << 1) | p1 -- reproduced, it is what the
+ * reference draws (`if (idx == 0) idx = idx >> 1` changes nothing). Weight = round(idx * 64 / 15) computed in float
+ * (linspace_idx), which is BC7's 4-bit weight table; channel = (e0 * (64 - w) + e1 * w + 32) >> 6, alpha in bits 24..31.
+ * ---------------------------------------------------------------------------------------------- */
+uint32_t pcr_oracle_decode_bc7(uint64_t point_index, const uint8_t *colors)
+{
+    uint64_t block = point_index / 16, local = point_index % 16;
+    uint64_t lo, hi;
+    memcpy(&lo, colors + block * 16, 8);
+    memcpy(&hi, colors + block * 16 + 8, 8);
+    uint32_t p0 = (uint32_t)(lo >> 63) & 1u, p1 = (uint32_t)hi & 1u;
+    uint32_t r0 = (((uint32_t)(lo >> 7) & 127u) << 1) | p0, r1 = (((uint32_t)(lo >> 14) & 127u) << 1) | p1;
+    uint32_t g0 = (((uint32_t)(lo >> 21) & 127u) << 1) | p0, g1 = (((uint32_t)(lo >> 28) & 127u) << 1) | p1;
+    uint32_t b0 = (((uint32_t)(lo >> 35) & 127u) << 1) | p0, b1 = (((uint32_t)(lo >> 42) & 127u) << 1) | p1;
+    uint32_t a0 = (((uint32_t)(lo >> 49) & 127u) << 1) | p0, a1 = (((uint32_t)(lo >> 56) & 127u) << 1) | p1;
+    int idx = (int)((hi >> (local * 4)) & 0xF);
+    float step = (64.0f - 0.0f) / (float)(16 - 1);          /* linspace_idx(0, 64, 16, idx), render.cu:113-118 */
+    float val = 0.0f + (float)idx * step;
+    uint32_t w = (uint32_t)(int)roundf(val), iw = 64u - w;
+    return ((uint32_t)(uint8_t)((r0 * iw + r1 * w + 32) >> 6)) |
+           ((uint32_t)(uint8_t)((g0 * iw + g1 * w + 32) >> 6) << 8) |
+           ((uint32_t)(uint8_t)((b0 * iw + b1 * w + 32) >> 6) << 16) |
+           ((uint32_t)(uint8_t)((a0 * iw + a1 * w + 32) >> 6) << 24);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Lane-accurate decode of one 32-lane cluster: render.cu:404-451. The GPU runs the 32 lanes in
  * lockstep; each symbol step ends with a ballot of the lanes whose current word ran dry, and those
  * lanes fetch consecutive stream words in ascending lane order. Reproduced including the tail
@@ -380,7 +410,8 @@ static void sink_raster(void *vctx, int chain, int i, int32_t cx, int32_t cy, in
         uint64_t old = c->fb[pix];
         float old_depth = bits_f32((uint32_t)(old >> 32));
         if ((double)pos.w <= (double)old_depth * 1.01) {             /* hqs render.cu:296 */
-            uint32_t rgba = pcr_oracle_decode_bc1(index, c->s->colors);
+            uint32_t rgba = c->s->color_format == PCR_COLOR_BC7 ? pcr_oracle_decode_bc7(index, c->s->colors)     /* :297-303 */
+                                                               : pcr_oracle_decode_bc1(index, c->s->colors);
             uint64_t r = rgba & 255u, g = (rgba >> 8) & 255u, b = (rgba >> 16) & 255u;
             c->rg[pix] += (r << 32) | g;                              /* :309-310 */
             c->ba[pix] += (b << 32) | 1u;                             /* :311-312 */
@@ -755,7 +786,8 @@ pcr_oracle_file *pcr_oracle_file_parse(const void *bytes, size_t n, char *err, s
     f->cluster_sizes = (int32_t *)calloc((size_t)nB * 32 + 1, 4);
     f->encoded = (uint32_t *)calloc((size_t)enc_words, 4);
     f->separate = (int32_t *)calloc((size_t)sep_words, 4);
-    f->colors = (uint8_t *)calloc((size_t)nB * PCR_COLOR_BYTES_PER_BATCH + 1, 1);
+    f->colors = (uint8_t *)calloc((size_t)nB * PCR_COLOR_BYTES_PER_BATCH_BC7 + 1, 1);      /* (room for either format) */
+    size_t color_bytes = 0;                                 /* of this file's records: the first record tells */
     if (!f->batches || !f->start_values || !f->separate_sizes || !f->dt_values || !f->dt_cwlen ||
         !f->cluster_sizes || !f->encoded || !f->separate || !f->colors) FAIL("out of memory");
 
@@ -786,13 +818,20 @@ pcr_oracle_file *pcr_oracle_file_parse(const void *bytes, size_t n, char *err, s
         memcpy(f->dt_cwlen + b * 4096, r + o, 4096 * 4); o += 4096 * 4;
         memcpy(f->cluster_sizes + b * 32, r + o, 32 * 4); o += 32 * 4;
         int64_t ne = f->cluster_sizes[b * 32 + 31], ns = f->separate_sizes[b * 1024 + 1023];
-        if (ne < 0 || ns < 0 || (size_t)size != fixed + 4u * (size_t)(ne + ns) + PCR_COLOR_BYTES_PER_BATCH)
+        /* BatchDumpData.h:130-136: the colour array of a record is 8 (BC1) or 16 (BC7 mode 6) bytes per 16 points, fixed
+         * when the reference is compiled (COLOR_COMPRESSION); here the record's size tells which */
+        if (ne < 0 || ns < 0) FAIL("batch %lld: negative stream sizes", (long long)b);
+        if (color_bytes == 0) {
+            if ((size_t)size == fixed + 4u * (size_t)(ne + ns) + PCR_COLOR_BYTES_PER_BATCH) color_bytes = PCR_COLOR_BYTES_PER_BATCH;
+            else if ((size_t)size == fixed + 4u * (size_t)(ne + ns) + PCR_COLOR_BYTES_PER_BATCH_BC7) color_bytes = PCR_COLOR_BYTES_PER_BATCH_BC7;
+        }
+        if (color_bytes == 0 || (size_t)size != fixed + 4u * (size_t)(ne + ns) + color_bytes)
             FAIL("batch %lld: record size mismatch", (long long)b);          /* BatchDumpData.h:148 */
         if (enc_ptr + ne > enc_words - PCR_ENCODED_PAD_WORDS || sep_ptr + ns > sep_words - PCR_SEPARATE_PAD_WORDS)
             FAIL("batch %lld: stream exceeds header byte counts", (long long)b);
         memcpy(f->encoded + enc_ptr, r + o, (size_t)ne * 4); o += (size_t)ne * 4;
         memcpy(f->separate + sep_ptr, r + o, (size_t)ns * 4); o += (size_t)ns * 4;
-        memcpy(f->colors + b * PCR_COLOR_BYTES_PER_BATCH, r + o, PCR_COLOR_BYTES_PER_BATCH);
+        memcpy(f->colors + (size_t)b * color_bytes, r + o, color_bytes);
 
         pcr_gpu_batch *g = &f->batches[b];      /* HuffmanLasLoader.cpp:188-211 */
         g->min_x = bmin[0]; g->min_y = bmin[1]; g->min_z = bmin[2];
@@ -815,5 +854,6 @@ pcr_oracle_file *pcr_oracle_file_parse(const void *bytes, size_t n, char *err, s
     f->s.separate = f->separate; f->s.separate_words = sep_words;
     f->s.separate_sizes = f->separate_sizes; f->s.dt_values = f->dt_values; f->s.dt_cwlen = f->dt_cwlen;
     f->s.cluster_sizes = f->cluster_sizes; f->s.colors = f->colors; f->s.batch_index_base = 0;
+    f->s.color_format = color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7 ? PCR_COLOR_BC7 : PCR_COLOR_BC1;
     return f;
 }

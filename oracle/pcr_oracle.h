@@ -38,8 +38,9 @@ typedef struct pcr_oracle_stream {
     const int32_t       *dt_values;        /* [nB*4096]       */
     const int32_t       *dt_cwlen;         /* [nB*4096]       */
     const int32_t       *cluster_sizes;    /* [nB*32] inclusive, batch-local   */
-    const uint8_t       *colors;           /* [nB*32768] BC1  */
+    const uint8_t       *colors;           /* [nB*32768] BC1 or [nB*65536] BC7 mode 6 */
     int64_t              batch_index_base; /* global index of batch 0 (colorize_chunks payload when sharded) */
+    int64_t              color_format;     /* PCR_COLOR_BC1 / PCR_COLOR_BC7 (0 reads as BC1) */
 } pcr_oracle_stream;
 
 enum { PCR_ORACLE_MEM_ITER = 0, PCR_ORACLE_HQS = 1 };
@@ -54,6 +55,7 @@ int pcr_oracle_batch_lod(const pcr_gpu_batch *b, const pcr_render_params *p, int
 void pcr_oracle_decode_batch(const pcr_oracle_stream *s, int64_t batch, int npr, int32_t *out_xyz);
 
 uint32_t pcr_oracle_decode_bc1(uint64_t point_index, const uint8_t *colors);
+uint32_t pcr_oracle_decode_bc7(uint64_t point_index, const uint8_t *colors);    /* BC7 mode 6 as the reference's kernels decode it */
 
 /* huffman_mem_iter_cuda/render.cu kernel over batches [first, first+count). fb has pcr_fb_elems(w,h) u64. */
 void pcr_oracle_render_basic(const pcr_oracle_stream *s, const pcr_render_params *p,

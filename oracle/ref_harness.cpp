@@ -7,6 +7,7 @@
 //     /root/reference/include/huffman.h      (Huffman<T>: tree, dictionary, table, packer, chain decoder)
 //     /root/reference/src/mymorton.h         (96-bit Morton key + stable order)
 //     /root/reference/include/rgbcx.h        (+ src/rgbcx.cpp linked: BC1 encoder/unpacker)
+//     /root/reference/include/bc7enc.h, bc7decomp.h (+ src/bc7enc.cpp, src/bc7decomp.cpp linked: BC7 encoder/unpacker)
 // and calls their functions. The reference's `preprocess`/BatchDumpData/loader cannot be built here
 // without stand-ins for GL/CUDA headers (compute/Resources.h -> Renderer.h, CudaProgram.h), so they are
 // treated as unbuildable and are restated instead.
@@ -18,6 +19,8 @@
 #include "huffman.h"     // reference: include/huffman.h
 #include "mymorton.h"    // reference: src/mymorton.h
 #include "rgbcx.h"       // reference: include/rgbcx.h
+#include "bc7enc.h"      // reference: include/bc7enc.h
+#include "bc7decomp.h"   // reference: include/bc7decomp.h
 
 namespace {
 struct RefCode {
@@ -32,6 +35,7 @@ template <class T> T *dup(const std::vector<T> &v)
     return p;
 }
 bool g_rgbcx_init = false;
+bool g_bc7_init = false;
 }
 
 extern "C" {
@@ -123,6 +127,24 @@ void ref_bc1_unpack(const uint8_t *block8, uint32_t *colors16)
 {
     if (!g_rgbcx_init) { rgbcx::init(rgbcx::bc1_approx_mode::cBC1Ideal); g_rgbcx_init = true; }
     rgbcx::unpack_bc1(block8, colors16, true, rgbcx::bc1_approx_mode::cBC1Ideal);
+}
+
+// src/bc7enc.cpp: encoder exactly as Chain::encode_color_bc7 calls it (src/preprocess.cpp:299-316: default parameters with
+// m_mode_mask = 1 << 6; bc7enc_compress_block_init() once, :1172)
+void ref_bc7_encode(const uint32_t *colors16, uint8_t *out16)
+{
+    if (!g_bc7_init) { bc7enc_compress_block_init(); g_bc7_init = true; }
+    uint32_t block[16];
+    std::memcpy(block, colors16, sizeof block);
+    bc7enc_compress_block_params params;
+    bc7enc_compress_block_params_init(&params);
+    params.m_mode_mask = 1 << 6;
+    bc7enc_compress_block(out16, (const uint8_t *)block, &params);
+}
+// src/bc7decomp.cpp: the specification's decoder (what src/preprocess.cpp:893-910 checks its blocks with)
+int ref_bc7_unpack(const uint8_t *block16, uint32_t *colors16)
+{
+    return bc7decomp::unpack_bc7(block16, (bc7decomp::color_rgba *)colors16) ? 1 : 0;
 }
 
 } // extern "C"

@@ -76,7 +76,7 @@ HIP_SYMBOLS = [
     "pcr_read_accum", "pcr_read_rgba", "pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba",
     "pcr_use_external_buffers", "pcr_merge_min", "pcr_merge_sum", "pcr_flip_sign", "pcr_timing_begin",
     "pcr_timing_end", "pcr_kernel_timing_enable", "pcr_kernel_timing_read", "pcr_measure_hbm",
-    "pcr_frame_begin", "pcr_frame_turn", "pcr_set_stream_layout", "pcr_set_render_variant", "pcr_set_int64_mergeable", "pcr_fence_record", "pcr_fence_wait", "pcr_merge_min_slices", "pcr_resolve_basic_range", "pcr_set_async_upload", "pcr_batches_resident", "pcr_last_frame_batches", "pcr_stream_algorithmic_bytes", "pcr_stream_resident_bytes", "pcr_kernel_version", "pcr_get_stream", "pcr_get_device", "pcr_framebuffer_elems",
+    "pcr_frame_begin", "pcr_frame_turn", "pcr_set_stream_layout", "pcr_set_render_variant", "pcr_set_int64_mergeable", "pcr_fence_record", "pcr_fence_wait", "pcr_merge_min_slices", "pcr_resolve_basic_range", "pcr_set_async_upload", "pcr_batches_resident", "pcr_last_frame_batches", "pcr_stream_algorithmic_bytes", "pcr_stream_resident_bytes", "pcr_stream_color_format", "pcr_kernel_version", "pcr_get_stream", "pcr_get_device", "pcr_framebuffer_elems",
     "pcr_las_begin", "pcr_las_upload", "pcr_las_unload", "pcr_las_batches_loaded", "pcr_render_las", "pcr_resolve_las",
     "pcr_las_algorithmic_bytes", "pcr_gpu_encode_points", "pcr_gpu_encode_free",
 ]
@@ -84,7 +84,7 @@ HIP_SYMBOLS = [
 HOST_SYMBOLS = [
     "pcr_host_last_error", "pcr_host_free", "pcr_encode_points", "pcr_synth_points", "pcr_synth_las_info",
     "pcr_synth_encode", "pcr_morton_key", "pcr_huffman_build", "pcr_pack_chain", "pcr_table_from_dict",
-    "pcr_bc1_encode_block", "pcr_las_quantize", "pcr_camera_orbit",
+    "pcr_bc1_encode_block", "pcr_bc7_encode_block", "pcr_las_quantize", "pcr_camera_orbit",
 ]
 
 _hip = None
@@ -157,6 +157,8 @@ def hip_lib() -> C.CDLL:
         lib.pcr_kernel_version.argtypes = []
         lib.pcr_stream_resident_bytes.restype = C.c_int64
         lib.pcr_stream_resident_bytes.argtypes = [C.c_void_p]
+        lib.pcr_stream_color_format.restype = C.c_int
+        lib.pcr_stream_color_format.argtypes = [C.c_void_p]
         lib.pcr_set_stream_layout.argtypes = [C.c_void_p, C.c_int]
         lib.pcr_set_render_variant.argtypes = [C.c_void_p, C.c_int]
         lib.pcr_set_int64_mergeable.argtypes = [C.c_void_p, C.c_int]
@@ -201,6 +203,8 @@ def host_lib() -> C.CDLL:
         lib.pcr_table_from_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p]
         lib.pcr_bc1_encode_block.argtypes = [C.c_void_p, C.c_void_p]
         lib.pcr_bc1_encode_block.restype = None
+        lib.pcr_bc7_encode_block.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pcr_bc7_encode_block.restype = None
         lib.pcr_las_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.POINTER(LasInfo), C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.pcr_camera_orbit.argtypes = [c_f64, c_f64, c_f64, C.POINTER(c_f64), C.c_int, C.c_int, c_f64, c_f64, c_f64,

@@ -41,7 +41,9 @@ struct pcr_ctx {
     int32_t *d_table_values = nullptr;
     int8_t *d_table_lens = nullptr;
     int32_t *d_cluster_sizes = nullptr;
-    uint8_t *d_colors = nullptr;
+    uint8_t *d_colors = nullptr;                // as uploaded (k_transcode's input; released with the other raw arrays)
+    uint8_t *d_colors_t = nullptr;              // segment-major copy k_render reads (StreamView::colors_t)
+    size_t color_bytes = 0;                     // per batch: PCR_COLOR_BYTES_PER_BATCH (BC1) or ..._BC7, told by the first record; 0 = not known yet
     uint32_t *d_lod = nullptr;
     WinPlan *d_win = nullptr;                   // LDS framebuffer windows of the frame's batches (prepass)
     uint32_t *d_batch_runs = nullptr;           // runs of chains and their bounding boxes, RUN_WORDS per batch (k_bounds)
@@ -166,14 +168,14 @@ void free_stream_buffers(pcr_ctx *c)
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     c->batches_resident = 0;
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
-    dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_lod); dfree(c->d_win);
+    dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_colors_t); dfree(c->d_lod); dfree(c->d_win);
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); dfree(c->d_batch_runs); c->transcoded = 0;
     dfree(c->d_order); dfree(c->d_chunk_count); dfree(c->d_any_generic); c->order_stride = 0;
     if (c->any_generic_pending && c->any_generic_ev) (void)hipEventSynchronize(c->any_generic_ev);
     c->any_generic_pending = false;
     if (c->h_any_generic) *c->h_any_generic = 0;
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0; c->prepass_ready = false;
-    c->finalized = false; c->lane_words_scratch = false; c->stream_bytes = 0;
+    c->finalized = false; c->lane_words_scratch = false; c->stream_bytes = 0; c->color_bytes = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
 }
 
@@ -224,7 +226,7 @@ StreamView make_stream_view(pcr_ctx *c)
     StreamView s;
     s.batches = c->d_batches; s.start_values = c->d_start; s.encoded = c->d_encoded;
     s.separate = c->d_separate; s.separate_sizes = c->d_sep_sizes; s.table_values = c->d_table_values;
-    s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors;
+    s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors; s.colors_t = c->d_colors_t; s.color_block_bytes = c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7 ? 16u : 8u;
     s.lane_words = c->d_lane_words; s.batch_flags = c->d_batch_flags; s.packed_table = c->d_packed_table;
     s.point_windows = c->d_point_windows; s.batch_runs = c->d_batch_runs;
     s.encoded_words = c->enc_words; s.separate_words = c->sep_words;
@@ -266,7 +268,7 @@ void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
         for (int64_t b0 = c->transcoded; b0 < end; ) {
             const int64_t n = c->lane_words_scratch ? std::min(TRANSCODE_CHUNK, end - b0) : end - b0;
             hipLaunchKernelGGL(k_transcode, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
-                               make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows,
+                               make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows, c->d_colors_t,
                                c->d_any_generic, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
             hipLaunchKernelGGL(k_bounds, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
                                make_stream_view(c), c->d_lane_words, c->d_batch_runs, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
@@ -301,6 +303,7 @@ int enable_big_lds(pcr_ctx *c)
     PCR_ALLOW(MODE_BASIC, LAYOUT_WORDS); PCR_ALLOW(MODE_BASIC, LAYOUT_POINT_WINDOWS);
     PCR_ALLOW(MODE_HQS_DEPTH, LAYOUT_WORDS); PCR_ALLOW(MODE_HQS_DEPTH, LAYOUT_POINT_WINDOWS);
     PCR_ALLOW(MODE_HQS_COLOR, LAYOUT_WORDS); PCR_ALLOW(MODE_HQS_COLOR, LAYOUT_POINT_WINDOWS);
+    PCR_ALLOW(MODE_HQS_COLOR_BC7, LAYOUT_WORDS); PCR_ALLOW(MODE_HQS_COLOR_BC7, LAYOUT_POINT_WINDOWS);
 #undef PCR_ALLOW
     if (e != hipSuccess) return set_err(c, PCR_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
     c->big_lds_ready = true;
@@ -320,6 +323,7 @@ void maybe_finalize(pcr_ctx *c)
     dfree_counted(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS);
     dfree_counted(c, c->d_table_lens, nB * 4096);
     dfree_counted(c, c->d_cluster_sizes, nB * 32);
+    dfree_counted(c, c->d_colors, nB * (c->color_bytes ? c->color_bytes : (size_t)PCR_COLOR_BYTES_PER_BATCH));     // k_render reads colors_t
     if (*c->h_any_generic == 0) dfree_counted(c, c->d_table_values, nB * 4096);
     if (c->lane_words_scratch) dfree_counted(c, c->d_lane_words, (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB) * LW_ROWS * PCR_WORKGROUP_SIZE);
     c->finalized = true;
@@ -335,7 +339,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
     maybe_finalize(c);
-    const int win_pixel_bytes = MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
+    const int win_pixel_bytes = (MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7) ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
     const int variant_hqs = MODE != MODE_BASIC;
     const uint32_t dyn_lds = frame_dyn_lds(c, nB);
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
@@ -387,7 +391,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r02.v64"; }
+const char *pcr_kernel_version(void) { return "r02.v66"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -494,7 +498,8 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words + PCR_GUARD_WORDS, acc)) ||
         (rc = dalloc_zero(c, c->d_sep_sizes, nB * 1024, acc)) || (rc = dalloc_zero(c, c->d_table_values, nB * 4096, acc)) ||
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096, acc)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32, acc)) ||
-        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) || (rc = dalloc_zero(c, c->d_lod, nB, acc)) ||
+        (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) || (rc = dalloc_zero(c, c->d_colors_t, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) ||
+        (rc = dalloc_zero(c, c->d_lod, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_win, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_lane_words, lw_batches * LW_ROWS * PCR_WORKGROUP_SIZE, acc)) || (rc = dalloc_zero(c, c->d_batch_flags, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
@@ -534,6 +539,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     struct View { const uint8_t *start, *sepsz, *tv, *tl, *cl, *enc, *sep, *col; int32_t ne, ns; };
     std::vector<View> views((size_t)count);
     int64_t sum_ne = 0, sum_ns = 0;
+    size_t color_bytes = c->color_bytes;
     // ---- pass 1: validate (nothing is modified if any record is bad) --------------------------------------------
     for (int64_t k = 0; k < count; ++k) {
         const int64_t bi = first_index + k;
@@ -557,7 +563,15 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
         v.enc = v.cl + 32 * 4;
         std::memcpy(&v.ne, v.cl + 31 * 4, 4);
         std::memcpy(&v.ns, v.sepsz + 1023 * 4, 4);
-        if (v.ne < 64 || v.ns < 0 || n != fixed + 4u * ((size_t)v.ne + (size_t)v.ns) + PCR_COLOR_BYTES_PER_BATCH)   // BatchDumpData.h:148
+        if (v.ne < 64 || v.ns < 0) return set_err(c, PCR_E_FORMAT, "batch %lld: stream lengths %d / %d", (long long)bi, v.ne, v.ns);
+        // BatchDumpData.h:130-136: 8 (BC1) or 16 (BC7 mode 6) colour bytes per 16 points, fixed when the reference is built
+        // (COLOR_COMPRESSION); here the first record of a stream tells which, and the others have to agree
+        const size_t streams = fixed + 4u * ((size_t)v.ne + (size_t)v.ns);
+        if (color_bytes == 0) {
+            if (n == streams + PCR_COLOR_BYTES_PER_BATCH) color_bytes = PCR_COLOR_BYTES_PER_BATCH;
+            else if (n == streams + PCR_COLOR_BYTES_PER_BATCH_BC7) color_bytes = PCR_COLOR_BYTES_PER_BATCH_BC7;
+        }
+        if (color_bytes == 0 || n != streams + color_bytes)                                                          // BatchDumpData.h:148
             return set_err(c, PCR_E_FORMAT, "batch %lld: record size %zu does not match its stream lengths", (long long)bi, n);
         v.sep = v.enc + (size_t)v.ne * 4;
         v.col = v.sep + (size_t)v.ns * 4;
@@ -577,6 +591,18 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
 
     // ---- pass 2: pack into the free pinned arena ------------------------------------------------------------------
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->color_bytes == 0) {
+        // the first records of the stream: its colour format is known now (the colour array was allocated for BC1)
+        if (color_bytes != PCR_COLOR_BYTES_PER_BATCH) {
+            const size_t nB = (size_t)c->hdr.num_batches;
+            dfree_counted(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH);
+            dfree_counted(c, c->d_colors_t, nB * PCR_COLOR_BYTES_PER_BATCH);
+            int rc = dalloc_zero(c, c->d_colors, nB * color_bytes, &c->stream_bytes);
+            if (!rc) rc = dalloc_zero(c, c->d_colors_t, nB * color_bytes, &c->stream_bytes);
+            if (rc) return rc;
+        }
+        c->color_bytes = color_bytes;
+    }
     const size_t nb = (size_t)count;
     const size_t o_batches = 0;
     const size_t o_start = o_batches + nb * sizeof(pcr_gpu_batch);
@@ -585,7 +611,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     const size_t o_tl = o_tv + nb * 4096 * 4;
     const size_t o_cl = o_tl + nb * 4096;
     const size_t o_col = o_cl + nb * 32 * 4;
-    const size_t o_enc = o_col + nb * PCR_COLOR_BYTES_PER_BATCH;
+    const size_t o_enc = o_col + nb * color_bytes;
     const size_t o_sep = o_enc + (size_t)sum_ne * 4;
     const size_t total = o_sep + (size_t)sum_ns * 4;
     const int slot = c->arena_next;
@@ -627,7 +653,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
         int8_t *tl8 = (int8_t *)(A + o_tl + kk * 4096);
         for (int i = 0; i < 4096; ++i) { int32_t l; std::memcpy(&l, v.tl + 4 * i, 4); tl8[i] = (int8_t)l; }   // render.cu:393
         std::memcpy(A + o_cl + kk * 32 * 4, v.cl, 32 * 4);
-        std::memcpy(A + o_col + kk * PCR_COLOR_BYTES_PER_BATCH, v.col, PCR_COLOR_BYTES_PER_BATCH);
+        std::memcpy(A + o_col + kk * color_bytes, v.col, color_bytes);
         std::memcpy(A + o_enc + eo, v.enc, (size_t)v.ne * 4); eo += (size_t)v.ne * 4;
         std::memcpy(A + o_sep + so, v.sep, (size_t)v.ns * 4); so += (size_t)v.ns * 4;
         enc_ptr += v.ne; sep_ptr += v.ns;
@@ -642,7 +668,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     HIP_TRY(c, hipMemcpyAsync(c->d_table_values + b0 * 4096, A + o_tv, nb * 4096 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_table_lens + b0 * 4096, A + o_tl, nb * 4096, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_cluster_sizes + b0 * 32, A + o_cl, nb * 32 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_colors + b0 * PCR_COLOR_BYTES_PER_BATCH, A + o_col, nb * PCR_COLOR_BYTES_PER_BATCH, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_colors + b0 * color_bytes, A + o_col, nb * color_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_encoded + c->enc_ptr, A + o_enc, (size_t)sum_ne * 4, hipMemcpyHostToDevice, st));
     if (sum_ns) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, A + o_sep, (size_t)sum_ns * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipEventRecord(c->arena_done[slot], st));
@@ -749,6 +775,11 @@ int64_t pcr_batches_resident(pcr_ctx *c)
 int64_t pcr_points_loaded(const pcr_ctx *c) { return c ? c->points_loaded : 0; }
 
 int64_t pcr_stream_resident_bytes(const pcr_ctx *c) { return c && c->stream_open ? (int64_t)c->stream_bytes : 0; }
+int pcr_stream_color_format(const pcr_ctx *c)
+{
+    if (!c || !c->stream_open || c->color_bytes == 0) return 0;
+    return c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7 ? PCR_COLOR_BC7 : PCR_COLOR_BC1;
+}
 
 int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
 {
@@ -878,12 +909,21 @@ int pcr_set_int64_mergeable(pcr_ctx *c, int on)
     return PCR_OK;
 }
 
-int pcr_render_basic(pcr_ctx *c, const pcr_render_params *p) { return launch_render<MODE_BASIC>(c, p); }
+int pcr_render_basic(pcr_ctx *c, const pcr_render_params *p)
+{
+    // COLOR_COMPRESSION == 7 is not a defined configuration of the reference's basic method: its rasterize decodes the colour
+    // array as BC1 whatever the setting (huffman_mem_iter_cuda/render.cu:299) and its resolve then indexes that array with
+    // the resulting COLOUR as if it were a point id (resolve.cu:183) -- an out-of-bounds read. Only the HQS method draws BC7.
+    if (c && c->stream_open && c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7)
+        return set_err(c, PCR_E_ARG, "the basic method is not defined for a stream with BC7 colours (use the HQS method)");
+    return launch_render<MODE_BASIC>(c, p);
+}
 int pcr_render_hqs_depth(pcr_ctx *c, const pcr_render_params *p) { return launch_render<MODE_HQS_DEPTH>(c, p); }
 int pcr_render_hqs_color(pcr_ctx *c, const pcr_render_params *p)
 {
     if (c && (!c->rg || !c->ba)) return set_err(c, PCR_E_ARG, "no RG/BA accumulation buffers");
     if (c) c->accum_dirty = true;
+    if (c->stream_open && c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7) return launch_render<MODE_HQS_COLOR_BC7>(c, p);
     return launch_render<MODE_HQS_COLOR>(c, p);
 }
 

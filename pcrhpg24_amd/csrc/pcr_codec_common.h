@@ -228,4 +228,78 @@ PCR_HD void bc1_encode(const uint32_t *pix, uint8_t *out)
     out[4] = (uint8_t)best.selectors; out[5] = (uint8_t)(best.selectors >> 8); out[6] = (uint8_t)(best.selectors >> 16); out[7] = (uint8_t)(best.selectors >> 24);
 }
 
+// BC7 mode-6 block of 16 colours (0x00BBGGRR), the colour format of the reference built with COLOR_COMPRESSION == 7
+// (src/preprocess.cpp:299-316 calls bc7enc with m_mode_mask = 1 << 6). Own encoder, integer arithmetic: endpoints = the ends
+// of the bounding box along the signs of the channels' covariance with the widest channel, each rounded to 7 bits + the
+// p-bit (shared by the endpoint's channels) with the smaller error, alpha 255; 4-bit indices = nearest of BC7's sixteen
+// weights on the segment; endpoints swapped when pixel 0's index would need its fourth bit (the anchor has three).
+// Layout (render.cu:66-110, struct bc7_mode_6): low quadword mode:7 (= 0x40) r0:7 r1:7 g0:7 g1:7 b0:7 b1:7 a0:7 a1:7 p0:1,
+// high quadword p1:1, index of pixel 0 :3, indices of pixels 1..15 :4 each.
+PCR_HD void bc7_mode6_encode(const uint32_t *pix, uint8_t *out)
+{
+    const int weights[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+    int px[16][3], mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0}, sum[3] = {0, 0, 0};
+    for (int i = 0; i < 16; ++i)
+        for (int c = 0; c < 3; ++c) {
+            px[i][c] = (int)((pix[i] >> (8 * c)) & 255u);
+            mn[c] = px[i][c] < mn[c] ? px[i][c] : mn[c]; mx[c] = px[i][c] > mx[c] ? px[i][c] : mx[c]; sum[c] += px[i][c];
+        }
+    int main_c = 0;
+    for (int c = 1; c < 3; ++c) if (mx[c] - mn[c] > mx[main_c] - mn[main_c]) main_c = c;
+    int e[2][3];
+    for (int c = 0; c < 3; ++c) {
+        long long cov = 0;
+        for (int i = 0; i < 16; ++i) cov += (long long)(16 * px[i][c] - sum[c]) * (16 * px[i][main_c] - sum[main_c]);
+        e[0][c] = cov >= 0 ? mn[c] : mx[c]; e[1][c] = cov >= 0 ? mx[c] : mn[c];
+    }
+    int q[2][3], pbit[2];
+    for (int k = 0; k < 2; ++k) {
+        int best_err = 1 << 30;
+        for (int pb = 0; pb < 2; ++pb) {
+            int err = 0, qq[3];
+            for (int c = 0; c < 3; ++c) {
+                int v = (e[k][c] - pb + 1) >> 1;
+                v = v < 0 ? 0 : v > 127 ? 127 : v;
+                qq[c] = v;
+                const int d = ((v << 1) | pb) - e[k][c];
+                err += d * d;
+            }
+            if (err < best_err) { best_err = err; pbit[k] = pb; for (int c = 0; c < 3; ++c) q[k][c] = qq[c]; }
+        }
+    }
+    int idx[16];
+    {
+        int r0[3], d[3], dd = 0;
+        for (int c = 0; c < 3; ++c) { r0[c] = (q[0][c] << 1) | pbit[0]; d[c] = ((q[1][c] << 1) | pbit[1]) - r0[c]; dd += d[c] * d[c]; }
+        for (int i = 0; i < 16; ++i) {
+            int best = 0, best_err = 1 << 30;
+            if (dd) {
+                for (int k = 0; k < 16; ++k) {
+                    int err = 0;
+                    for (int c = 0; c < 3; ++c) {
+                        const int v = ((r0[c] * (64 - weights[k]) + (r0[c] + d[c]) * weights[k] + 32) >> 6) - px[i][c];
+                        err += v * v;
+                    }
+                    if (err < best_err) { best_err = err; best = k; }
+                }
+            }
+            idx[i] = best;
+        }
+    }
+    if (idx[0] >= 8) {                                      // the anchor index has three bits: swap the endpoints
+        for (int c = 0; c < 3; ++c) { const int t = q[0][c]; q[0][c] = q[1][c]; q[1][c] = t; }
+        const int t = pbit[0]; pbit[0] = pbit[1]; pbit[1] = t;
+        for (int i = 0; i < 16; ++i) idx[i] = 15 - idx[i];
+    }
+    unsigned long long lo = 0x40ull, hi = 0;
+    lo |= (unsigned long long)q[0][0] << 7;  lo |= (unsigned long long)q[1][0] << 14;
+    lo |= (unsigned long long)q[0][1] << 21; lo |= (unsigned long long)q[1][1] << 28;
+    lo |= (unsigned long long)q[0][2] << 35; lo |= (unsigned long long)q[1][2] << 42;
+    lo |= 127ull << 49; lo |= 127ull << 56; lo |= (unsigned long long)pbit[0] << 63;
+    hi |= (unsigned long long)pbit[1];
+    hi |= (unsigned long long)idx[0] << 1;
+    for (int i = 1; i < 16; ++i) hi |= (unsigned long long)idx[i] << (4 * i);
+    for (int k = 0; k < 8; ++k) { out[k] = (uint8_t)(lo >> (8 * k)); out[8 + k] = (uint8_t)(hi >> (8 * k)); }
+}
+
 } // namespace pcr_codec

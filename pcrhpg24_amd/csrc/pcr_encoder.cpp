@@ -156,7 +156,7 @@ void put(std::vector<uint8_t> &buf, const void *p, size_t n)
 
 // x,y,z,color: 65536 points of this batch in final order. Appends one batch record to `rec`.
 int encode_batch(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color,
-                 int32_t point_offset, const pcr_las_info &las, bool pad_tails, std::vector<uint8_t> &rec, BatchStats &st)
+                 int32_t point_offset, const pcr_las_info &las, bool pad_tails, bool bc7, std::vector<uint8_t> &rec, BatchStats &st)
 {
     const int NT = PCR_WORKGROUP_SIZE, PPT = PCR_POINTS_PER_THREAD, N = PCR_POINTS_PER_BATCH;
     std::vector<int32_t> deltas((size_t)N * 3);
@@ -248,9 +248,10 @@ int encode_batch(const int32_t *x, const int32_t *y, const int32_t *z, const uin
     st.enc_words = (int64_t)encoding.size();
     st.sep_words = (int64_t)separate.size();
 
-    // BC1 colours, chain-major == point order (preprocess.cpp:1123-1128)
-    std::vector<uint8_t> bc1(PCR_COLOR_BYTES_PER_BATCH);
-    for (int blk = 0; blk < N / 16; ++blk) bc1_encode(color + blk * 16, &bc1[(size_t)blk * 8]);
+    // BC1 colours, chain-major == point order (preprocess.cpp:1123-1128); or BC7 mode 6 (:1129-1138, COLOR_COMPRESSION == 7)
+    std::vector<uint8_t> bc1(bc7 ? PCR_COLOR_BYTES_PER_BATCH_BC7 : PCR_COLOR_BYTES_PER_BATCH);
+    if (bc7) for (int blk = 0; blk < N / 16; ++blk) pcr_codec::bc7_mode6_encode(color + blk * 16, &bc1[(size_t)blk * 16]);
+    else     for (int blk = 0; blk < N / 16; ++blk) bc1_encode(color + blk * 16, &bc1[(size_t)blk * 8]);
 
     // record (include/BatchDumpData.h:151-202)
     int32_t hdr[5] = {point_offset, N, NT, PPT, PCR_CLUSTERS_PER_THREAD};
@@ -292,7 +293,7 @@ struct ChunkOut {
 int encode_chunk(std::vector<int32_t> &x, std::vector<int32_t> &y, std::vector<int32_t> &z,
                  std::vector<uint32_t> &c, const pcr_las_info &las, int flags, ChunkOut &out)
 {
-    const bool sort = (flags & PCR_ENCODE_MORTON_SORT) != 0, pad_tails = (flags & PCR_ENCODE_PAD_TAILS) != 0;
+    const bool sort = (flags & PCR_ENCODE_MORTON_SORT) != 0, pad_tails = (flags & PCR_ENCODE_PAD_TAILS) != 0, bc7 = (flags & PCR_ENCODE_BC7) != 0;
     if (x.empty()) return fail("empty chunk");
     size_t n = x.size();
     size_t extra = (n % PCR_POINTS_PER_BATCH) ? PCR_POINTS_PER_BATCH - (n % PCR_POINTS_PER_BATCH) : 0;
@@ -323,7 +324,7 @@ int encode_chunk(std::vector<int32_t> &x, std::vector<int32_t> &y, std::vector<i
     for (size_t b = 0; b * PCR_POINTS_PER_BATCH < n; ++b) {
         size_t o = b * PCR_POINTS_PER_BATCH, before = out.bytes.size();
         BatchStats st;
-        if (encode_batch(&x[o], &y[o], &z[o], &c[o], (int32_t)o, las, pad_tails, out.bytes, st)) return -1;
+        if (encode_batch(&x[o], &y[o], &z[o], &c[o], (int32_t)o, las, pad_tails, bc7, out.bytes, st)) return -1;
         out.batch_sizes.push_back((int64_t)(out.bytes.size() - before));
         out.enc_words += st.enc_words; out.sep_words += st.sep_words; out.escaped += st.escaped;
     }
@@ -513,6 +514,7 @@ void pcr_morton_key(uint32_t x, uint32_t y, uint32_t z, uint32_t *hi, uint64_t *
 }
 
 void pcr_bc1_encode_block(const uint32_t *colors16, uint8_t *out8) { bc1_encode(colors16, out8); }
+void pcr_bc7_encode_block(const uint32_t *colors16, uint8_t *out16) { pcr_codec::bc7_mode6_encode(colors16, out16); }
 
 int pcr_encode_points(const int32_t *x, const int32_t *y, const int32_t *z, const uint32_t *color,
                       int64_t n, const pcr_las_info *las, int flags, int64_t chunk_points,

@@ -26,7 +26,7 @@ constexpr uint32_t LOD_NPR_MASK = 0xFFu;
 constexpr uint32_t LOD_DOUBLE   = 0x100u;
 constexpr uint32_t LOD_CULLED   = 0x200u;
 
-enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2 };
+enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2, MODE_HQS_COLOR_BC7 = 3 };   // (3: the colour pass over BC7 mode-6 colours)
 
 // k_render's LDS plan (76 KiB per 1024-thread workgroup -> two workgroups per CU)
 constexpr int CHUNK_WORDS    = 64;               // stream staging granule per cluster: 32 lanes x 2 words (8-byte loads)
@@ -107,7 +107,11 @@ struct StreamView {
     const int32_t  *table_values;     // [nB*4096]
     const int8_t   *table_lens;       // [nB*4096]
     const int32_t  *cluster_sizes;    // [nB*32]
-    const uint8_t  *colors;           // [nB*32768]
+    const uint8_t  *colors;           // [nB*32768] BC1 (or [nB*65536] BC7 mode 6) as the file has them: block 4 t + s = points 16 s .. 16 s + 15 of chain t
+    const uint8_t  *colors_t;         // the same blocks, k_transcode's order: [batch][segment s][chain t] -- the 1024 lanes of
+                                      // k_render read the blocks of one segment side by side (as the file has them a wave's 64
+                                      // blocks lie 32 B apart and every 128-byte line was fetched once per segment: 4x)
+    uint32_t color_block_bytes;       // 8 (BC1) / 16 (BC7)
     const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
@@ -475,6 +479,32 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
     return __builtin_amdgcn_perm(p.b, rg, (sel << 16) + 0x0c040100u);                          // b[sel] << 16 | rg
 }
 
+// BC7 mode-6 block as the reference's kernels decode it (huffman_hqs/render.cu:240-273, struct bc7_mode_6 render.cu:66-110):
+// endpoints = 7 bits << 1 | p-bit, the 4-bit field at 4 * local of the high quadword as the index of EVERY pixel (so pixel 0
+// gets index << 1 | p1: reproduced), weight = round(idx * 64 / 15) = (idx * 64 + 7) / 15, channel = (e0 (64 - w) + e1 w + 32) >> 6.
+// Kept per 16-point block as: r | b << 16 of endpoint 0, of endpoint 1, g0 | g1 << 16, and the two index words.
+struct Bc7Block { uint32_t rb0, rb1, g01, idx_lo, idx_hi; };
+__device__ __forceinline__ Bc7Block bc7_block(uint4 blk)
+{
+    const uint64_t lo = ((uint64_t)blk.y << 32) | blk.x;
+    const uint32_t p0 = blk.y >> 31, p1 = blk.z & 1u;
+    auto end = [&](int shift, uint32_t pbit) { return ((((uint32_t)(lo >> shift)) & 127u) << 1) | pbit; };
+    Bc7Block k;
+    k.rb0 = end(7, p0) | (end(35, p0) << 16);
+    k.rb1 = end(14, p1) | (end(42, p1) << 16);
+    k.g01 = end(21, p0) | (end(28, p1) << 16);
+    k.idx_lo = blk.z; k.idx_hi = blk.w;
+    return k;
+}
+__device__ __forceinline__ uint32_t bc7_color(const Bc7Block &k, uint32_t local)        // 0x00BBGGRR (the pass has no use for alpha)
+{
+    const uint32_t idx = ((local < 8u ? k.idx_lo : k.idx_hi) >> (4u * (local & 7u))) & 15u;
+    const uint32_t w = ((idx * 64u + 7u) * 4370u) >> 16, iw = 64u - w;                  // (n / 15 for the sixteen n = 64 idx + 7)
+    const uint32_t rb = ((k.rb0 * iw + k.rb1 * w + 0x00200020u) >> 6) & 0x00FF00FFu;
+    const uint32_t g = (((k.g01 & 0xFFFFu) * iw + (k.g01 >> 16) * w + 32u) >> 6) & 0xFFu;
+    return rb | (g << 8);
+}
+
 // Row/column of linear index i in a window of width ww (i < 2^23): one float multiply and a correction of at most one
 // row instead of a 32-bit integer division (which costs ~25 VALU on this hardware and sat in every set-up and merge).
 __device__ __forceinline__ void window_row_col(uint32_t i, uint32_t ww, float inv_ww, uint32_t &y, uint32_t &x)
@@ -510,11 +540,23 @@ __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lby
 // without checking (batch_flags).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
-                                                                  uint32_t *packed_table, uint8_t *point_windows,
+                                                                  uint32_t *packed_table, uint8_t *point_windows, uint8_t *colors_t,
                                                                   uint32_t *any_generic, int first_batch, int lane_words_first)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
+    // my chain's four colour blocks -> segment-major order (StreamView::colors_t)
+    if (s.color_block_bytes == 16) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(s.colors) + ((size_t)b * 4096 + tid * 4);
+        uint4 *dst = reinterpret_cast<uint4 *>(colors_t) + (size_t)b * 4096 + tid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k * PCR_WORKGROUP_SIZE] = src[k];
+    } else {
+        const uint2 *src = reinterpret_cast<const uint2 *>(s.colors) + ((size_t)b * 4096 + tid * 4);
+        uint2 *dst = reinterpret_cast<uint2 *>(colors_t) + (size_t)b * 4096 + tid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k * PCR_WORKGROUP_SIZE] = src[k];
+    }
     __shared__ __align__(16) uint8_t s_len[PCR_HUFFMAN_TABLE_SIZE];
     __shared__ __align__(16) uint32_t s_ring[PCR_CLUSTERS_PER_BATCH * RING_WORDS];
     bool generic = false;
@@ -775,6 +817,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int MODE, int LAYOUT, bool GENERIC>
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two workgroups per CU -> <= 64 VGPRs
 {
+    constexpr bool COLOR_PASS = MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7, BC7 = MODE == MODE_HQS_COLOR_BC7;
     // second level of the compaction: which batch is the blockIdx.x-th of my list? Every wave works it out for itself (a
     // 64-lane inclusive prefix sum over the chunk counts, 64 chunks = 2048 batches per round): no barrier, no LDS.
     uint32_t b;
@@ -841,7 +884,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // batches that do not fit, go to global memory (slow variant of the decode step).
     const uint32_t esc_lds = esc_pool_words(esc_total);
     unsigned long long *const s_win = reinterpret_cast<unsigned long long *>(s_dyn + esc_pool_bytes(esc_lds));
-    const uint32_t win_cap = (uint32_t)window_capacity(esc_total, MODE == MODE_HQS_COLOR ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES, a.dyn_lds_bytes);
+    const uint32_t win_cap = (uint32_t)window_capacity(esc_total, COLOR_PASS ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES, a.dyn_lds_bytes);
     {   // all loads of a thread in flight together, requested before the batch's escape count is known (7 per thread)
         int32_t v[ESC_POOL_EAGER / PCR_WORKGROUP_SIZE];
 #pragma unroll
@@ -902,7 +945,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             base += n;
         }
     };
-    if (MODE != MODE_HQS_COLOR) {
+    if (!COLOR_PASS) {
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) s_win[i] = ~0ull;
     } else {
         // colour pass: the depths of the rectangles as the depth pass left them, sums zeroed
@@ -962,10 +1005,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     // BC1 blocks of my chain (4 blocks of 16 points, 8 bytes each): the block of the current 16-point segment in
     // registers, the next one prefetched a whole segment (16 iterations) before its first use
-    const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors) + ((size_t)b * 4096 + tid * 4);
+    const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors_t) + ((size_t)b * 4096 + tid);          // [segment][chain]
     Bc1Palette pal = {0, 0, 0, 0};
     uint2 cnext = make_uint2(0, 0);
-    if (MODE != MODE_HQS_DEPTH) cnext = cblocks[0];
+    if (MODE != MODE_HQS_DEPTH && !BC7) cnext = cblocks[0];
+    // (BC7 colours, 16 bytes per block: the block of a segment is read at its start -- no register for a prefetched one)
+    const uint4 *blocks7 = reinterpret_cast<const uint4 *>(a.s.colors_t) + ((size_t)b * 4096 + tid);
+    Bc7Block pal7 = {0, 0, 0, 0, 0};
 
     // Second half of rasterize() (render.cu:297-301 / depth.cu:148-151 / hqs render.cu:292-313) for the point whose
     // framebuffer word `old` was fetched one iteration earlier, from the LDS window (widx) or from global memory.
@@ -992,11 +1038,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // LDS and the global path costs no vector instruction. The window word of the pixel: `wp` (basic / depth pass) or the
     // index `w` (colour pass: three planes).
     auto scatter = [&](bool valid, bool off, uint32_t pix, uint32_t w, unsigned long long *wp, uint32_t depth, uint64_t old, int point) __attribute__((always_inline)) {
-        if (MODE == MODE_HQS_COLOR) {
+        if (COLOR_PASS) {
             const float pw = __uint_as_float(depth);
             const float old_depth = __uint_as_float((uint32_t)(old >> 32));
             if (valid && (double)pw <= (double)old_depth * 1.01) {          // hqs render.cu:296
-                const uint32_t rgba = bc1_color(pal, (uint32_t)point & 15u);
+                const uint32_t rgba = BC7 ? bc7_color(pal7, (uint32_t)point & 15u) : bc1_color(pal, (uint32_t)point & 15u);
                 const uint32_t vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);   // r << 16 | g  (rgba = 0x00BBGGRR)
                 const uint32_t vbc = (rgba & 0x00FF0000u) | 1u;                        // b << 16 | 1
                 // Consecutive points of a chain are Morton neighbours and mostly land in the same pixel: their
@@ -1060,7 +1106,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // (tools/exp/instr_rate2.hip). The kernel has the registers to spare (<= 64 for eight waves per SIMD).
     // (only where there are registers to spare: not in the colour pass, which keeps its run of sums in registers, not with
     // the packed-words variant's five-word queue, not in the checked variant)
-    constexpr bool VGPR_CONSTANTS = MODE != MODE_HQS_COLOR && LAYOUT == LAYOUT_POINT_WINDOWS && !GENERIC;
+    constexpr bool VGPR_CONSTANTS = !COLOR_PASS && LAYOUT == LAYOUT_POINT_WINDOWS && !GENERIC;
     auto in_vgpr_f = [](float v) { if (!VGPR_CONSTANTS) return v; float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     auto in_vgpr_u = [](uint32_t v) { if (!VGPR_CONSTANTS) return v; uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     const float m30 = in_vgpr_f(M[12]), m31 = in_vgpr_f(M[13]), m32 = in_vgpr_f(M[14]), m33 = in_vgpr_f(M[15]);   // the w row
@@ -1145,8 +1191,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
       scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, seg - 1);
       pend_valid = false;
       if (MODE != MODE_HQS_DEPTH) {
-          pal = bc1_palette(cnext);                     // once per 16 points instead of once per surviving point
-          cnext = cblocks[min((seg >> 4) + 1, 3)];
+          if (BC7) pal7 = bc7_block(blocks7[(seg >> 4) * PCR_WORKGROUP_SIZE]);
+          else {
+              pal = bc1_palette(cnext);                 // once per 16 points instead of once per surviving point
+              cnext = cblocks[min((seg >> 4) + 1, 3) * PCR_WORKGROUP_SIZE];
+          }
       }
       const int seg_end = min(seg + 16, npr_run);
 #pragma unroll 1
@@ -1181,7 +1230,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
             // word has been in flight since the end of the last iteration
             // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
-            if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+            if (!COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
             sft -= e1;
             const uint32_t toff2 = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
             const uint32_t e2 = table_entry(toff2);
@@ -1191,11 +1240,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             constexpr std::integral_constant<bool, false> table_first{};
             constexpr std::integral_constant<bool, true> escape_first{};
             d0 = symbol_step(table_first);                                  // :430
-            if (MODE != MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+            if (!COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
             d1 = symbol_step(table_first);
             d2 = symbol_step(escape_first);
         }
-        if (MODE == MODE_HQS_COLOR) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+        if (COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
         pz = (int32_t)((uint32_t)pz + d2);
@@ -1254,12 +1303,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             bool in_window = false, off_window = false;
             if (inside) {
                 pend_depth = __float_as_uint(qw);                                       // :287
-                if (MODE == MODE_HQS_COLOR) pend_pix = (uint32_t)(ix + iy * img_w);     // the colour pass names its runs by pixel
+                if (COLOR_PASS) pend_pix = (uint32_t)(ix + iy * img_w);     // the colour pass names its runs by pixel
                 const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
                 in_window = rx < ww && ry < wh;
                 off_window = !in_window;
                 // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
-                if (MODE == MODE_HQS_COLOR) pend_w = wbase + (in_window ? ry * ww + rx : 0u); else pend_p = s_win_mine + (in_window ? ry * ww + rx : 0u);
+                if (COLOR_PASS) pend_w = wbase + (in_window ? ry * ww + rx : 0u); else pend_p = s_win_mine + (in_window ? ry * ww + rx : 0u);
             }
             pend_valid = inside;
             pend_off = off_window;
@@ -1268,7 +1317,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             // waits for the look-ahead table entry alone (lgkmcnt(1)) instead of for this read as well.
             // (The global load comes second: a load into the same registers issued behind the LDS read only has to wait for the
             // LDS counter, the other way round the LDS read would wait for every vector-memory load in flight.)
-            pend_old = MODE == MODE_HQS_COLOR ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
+            pend_old = COLOR_PASS ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
             if (off_window) {
                 pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
                 // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
@@ -1304,14 +1353,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
       }
     }
     scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, npr_run - 1);
-    if (MODE == MODE_HQS_COLOR) flush_run();
+    if (COLOR_PASS) flush_run();
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
     if (wpix) {
         __syncthreads();
         for_window_pixels([&](uint32_t i, size_t gp) {
-            if (MODE == MODE_HQS_COLOR) {
+            if (COLOR_PASS) {
                 const unsigned long long vba = s_ba[i];
                 if (vba) {
                     atomicAdd((unsigned long long *)&a.f.rg[gp], s_rg[i]);

@@ -104,14 +104,15 @@ def synth_las_info(total_points: int, seed: int = 0x5EED) -> LasInfo:
 
 
 def encode_points(x, y, z, color, las: LasInfo, morton_sort: bool = True, chunk_points: int = 0,
-                  nthreads: int = 0, pad_tails: bool = False) -> tuple[NativeBytes, dict]:
+                  nthreads: int = 0, pad_tails: bool = False, bc7: bool = False) -> tuple[NativeBytes, dict]:
     """`preprocess in.las out.huffman <sort>` on in-memory points (src/preprocess.cpp:1167-1279). pad_tails: the
-    PCR_ENCODE_PAD_TAILS variant (not in the reference) whose streams decode without the tail artefact."""
+    PCR_ENCODE_PAD_TAILS variant (not in the reference) whose streams decode without the tail artefact. bc7: colours as BC7
+    mode-6 blocks, the file of a reference built with COLOR_COMPRESSION == 7 (PCR_ENCODE_BC7)."""
     x = np.ascontiguousarray(x, np.int32); y = np.ascontiguousarray(y, np.int32); z = np.ascontiguousarray(z, np.int32)
     color = np.ascontiguousarray(color, np.uint32)
     out, ln, st = C.c_void_p(), C.c_size_t(), EncodeStats()
     rc = N.host_lib().pcr_encode_points(x.ctypes.data, y.ctypes.data, z.ctypes.data, color.ctypes.data, len(x), C.byref(las),
-                                        int(bool(morton_sort)) | (2 if pad_tails else 0), chunk_points, nthreads,
+                                        int(bool(morton_sort)) | (2 if pad_tails else 0) | (4 if bc7 else 0), chunk_points, nthreads,
                                         C.byref(out), C.byref(ln), C.byref(st))
     if rc:
         raise PcrError(f"pcr_encode_points: {N.host_error()}")
@@ -318,6 +319,10 @@ class Context:
     def resident_bytes(self) -> int:
         """Device bytes the loaded stream occupies right now (pcr_stream_resident_bytes)."""
         return int(self.lib.pcr_stream_resident_bytes(self.h))
+
+    def stream_color_format(self) -> int:
+        """1 (BC1) / 7 (BC7 mode 6) / 0 before the first record (pcr_stream_color_format)."""
+        return int(self.lib.pcr_stream_color_format(self.h))
 
     def gpu_encode_points(self, x, y, z, color, las: LasInfo, morton_sort: bool = True, chunk_points: int = 0,
                           pad_tails: bool = False) -> tuple[NativeBytes, dict]:

@@ -43,6 +43,8 @@ def lib() -> C.CDLL:
         L.pcr_oracle_batch_lod.argtypes = [C.POINTER(GpuBatch), C.POINTER(RenderParams), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.pcr_oracle_decode_bc1.restype = C.c_uint32
         L.pcr_oracle_decode_bc1.argtypes = [C.c_uint64, C.c_void_p]
+        L.pcr_oracle_decode_bc7.restype = C.c_uint32
+        L.pcr_oracle_decode_bc7.argtypes = [C.c_uint64, C.c_void_p]
         for n in ("pcr_oracle_render_basic", "pcr_oracle_render_hqs_depth"):
             getattr(L, n).argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int64, C.c_int64, C.c_void_p, C.POINTER(RenderStats)]
             getattr(L, n).restype = None
@@ -75,7 +77,7 @@ class OracleStreamStruct(C.Structure):
                 ("encoded", C.c_void_p), ("encoded_words", C.c_int64), ("separate", C.c_void_p),
                 ("separate_words", C.c_int64), ("separate_sizes", C.c_void_p), ("dt_values", C.c_void_p),
                 ("dt_cwlen", C.c_void_p), ("cluster_sizes", C.c_void_p), ("colors", C.c_void_p),
-                ("batch_index_base", C.c_int64)]
+                ("batch_index_base", C.c_int64), ("color_format", C.c_int64)]
 
 
 class OracleFile:
@@ -184,6 +186,10 @@ def resolve_hqs(p: RenderParams, fb, rg, ba) -> np.ndarray:
 
 def decode_bc1(index: int, colors: np.ndarray) -> int:
     return int(lib().pcr_oracle_decode_bc1(index, colors.ctypes.data))
+
+
+def decode_bc7(index: int, colors: np.ndarray) -> int:
+    return int(lib().pcr_oracle_decode_bc7(index, colors.ctypes.data))
 
 
 def decode_chain(words, separate, dt_values, dt_cwlen, n: int) -> np.ndarray:

@@ -38,6 +38,9 @@ def ref_lib() -> C.CDLL:
         L.ref_morton_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ref_bc1_encode.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_bc1_unpack.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_bc7_encode.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_bc7_unpack.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_bc7_unpack.restype = C.c_int
         _ref = L
     return _ref
 

@@ -106,6 +106,35 @@ def bc1_ref():
     print("bc1:", enc.shape)
 
 
+def bc7_ref():
+    """Seeded colours, the BC7 mode-6 blocks the REFERENCE encoder makes of them (src/bc7enc.cpp, called as Chain::encode_color_bc7
+    does, src/preprocess.cpp:299-316) and what the reference's CPU decoder (src/bc7decomp.cpp) unpacks them to."""
+    ref = refpin.ref_lib()
+    rng = np.random.default_rng(4321)
+    blocks = []
+    for k in range(256):
+        base = rng.integers(0, 256, 3)
+        if k % 4 == 0:
+            cols = np.tile(base, (16, 1))
+        elif k % 4 == 1:
+            cols = np.clip(base + rng.integers(-12, 13, (16, 3)), 0, 255)
+        elif k % 4 == 2:
+            other = rng.integers(0, 256, 3)
+            t = rng.random((16, 1))
+            cols = (base * (1 - t) + other * t).astype(np.int64)
+        else:
+            cols = rng.integers(0, 256, (16, 3))
+        blocks.append((cols[:, 0] | (cols[:, 1] << 8) | (cols[:, 2] << 16) | (255 << 24)).astype(np.uint32))
+    colors = np.stack(blocks)
+    enc = np.zeros((len(colors), 16), np.uint8)
+    unp = np.zeros((len(colors), 16), np.uint32)
+    for i in range(len(colors)):
+        ref.ref_bc7_encode(colors[i].ctypes.data, enc[i].ctypes.data)
+        assert ref.ref_bc7_unpack(enc[i].ctypes.data, unp[i].ctypes.data) == 1
+    np.savez_compressed(os.path.join(G, "bc7_ref_blocks.npz"), colors=colors, blocks=enc, unpacked=unp)
+    print("bc7:", enc.shape, "modes", sorted(set(int(b[0]) & 0x7F for b in enc)))
+
+
 def huffman_ref():
     rng = np.random.default_rng(99)
     cases = {}
@@ -290,9 +319,14 @@ def ref_packed_batch():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # only the named fixtures: python tools/make_golden.py bc7_ref ...
+        for name in sys.argv[1:]:
+            {"config1": config1, "bc1_ref": bc1_ref, "bc7_ref": bc7_ref, "huffman_ref": huffman_ref, "ref_packed_batch": ref_packed_batch}[name]()
+        sys.exit(0)
     config1()
     if os.path.exists(oracle.REF_LIB):
         bc1_ref()
+        bc7_ref()
         huffman_ref()
         ref_packed_batch()
     else:
