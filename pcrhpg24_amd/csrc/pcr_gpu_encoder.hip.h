@@ -377,6 +377,7 @@ extern "C" int pcr_gpu_encode_points(pcr_ctx *c, const int32_t *x, const int32_t
     if (!c) return PCR_E_ARG;
     if (!x || !y || !z || !color || !las || !out_bytes || !out_len) return set_err(c, PCR_E_ARG, "null argument");
     if (n <= 0) return set_err(c, PCR_E_ARG, "no points");
+    if (flags & PCR_ENCODE_BC7) return set_err(c, PCR_E_ARG, "BC7 colours are written by the CPU encoder only (pcr_encode_points)");
     if (chunk_points <= 0) chunk_points = PCR_DEFAULT_CHUNK_POINTS;
     if (chunk_points % NPB) return set_err(c, PCR_E_ARG, "chunk_points must be a multiple of %d", NPB);
     if (chunk_points / NPB > 1024)      // scratch is sized per chunk (16 MB per batch) and the sorts index it with 32-bit ints

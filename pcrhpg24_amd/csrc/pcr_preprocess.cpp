@@ -13,13 +13,14 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) { std::fprintf(stderr, "usage: pcr_preprocess <in.las> <out.huffman> <sort 0|1> [threads] [--pad-tails] [--gpu]\n"); return 2; }   // preprocess.cpp:1169-1180
+    if (argc < 4) { std::fprintf(stderr, "usage: pcr_preprocess <in.las> <out.huffman> <sort 0|1> [threads] [--pad-tails] [--bc7] [--gpu]\n"); return 2; }   // preprocess.cpp:1169-1180
     const std::string in = argv[1], out = argv[2];
     int flags = std::atoi(argv[3]) ? PCR_ENCODE_MORTON_SORT : 0;
     int threads = 0;
     bool gpu = false;
     for (int i = 4; i < argc; ++i) {
         if (std::string(argv[i]) == "--pad-tails") flags |= PCR_ENCODE_PAD_TAILS;   // not in the reference, see pcr_encode.h
+        else if (std::string(argv[i]) == "--bc7") flags |= PCR_ENCODE_BC7;         // the reference built with COLOR_COMPRESSION == 7
         else if (std::string(argv[i]) == "--gpu") gpu = true;                       // pcr_gpu_encode_points: same bytes, encoded on the MI355X
         else threads = std::atoi(argv[i]);
     }
