@@ -96,6 +96,28 @@ def test_escape_pool_overflow_and_lod_zero(ctx):
         check_all(ctx, of, p)
 
 
+def test_batches_that_fall_apart_into_clusters_get_a_window_per_run(ctx):
+    """Batches whose points are clusters far apart (a jump of the Morton curve inside the batch, even inside one chain): their
+    bounding rectangle covers most of the screen and fits no LDS window, so the prepass gives every run of chains its own
+    (k_bounds + plan_windows); chains that straddle a jump scatter through global memory. Any plan has to give the oracle's frame."""
+    rng = np.random.default_rng(77)
+    n = 300_000
+    centres = np.array([[50_000, 60_000, 2_000], [900_000, 80_000, 9_000], [120_000, 950_000, 4_000], [880_000, 900_000, 1_000], [500_000, 500_000, 30_000]])
+    which = rng.integers(0, len(centres), n)
+    xyz = centres[which] + rng.normal(0, [6_000, 6_000, 800], (n, 3))
+    x, y, z = (np.clip(xyz[:, k], 0, 1_000_000).astype(np.int32) for k in range(3))
+    c = rng.integers(0, 1 << 24, n, dtype=np.int64).astype(np.uint32)
+    image, st = P.encode_points(x, y, z, c, las_for((0, 0, 0), (1_000_000, 1_000_000, 40_000)), morton_sort=True, nthreads=2)
+    of = oracle.OracleFile(image.view())
+    for w, h in ((1920, 1080), (640, 360)):
+        ctx.set_image_size(w, h)
+        load(ctx, image)
+        for p in (P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 20.0), w, h), P.camera_orbit(0.8, -1.1, 1100.0, (500.0, 500.0, 20.0), w, h)):
+            for lod in (100, 10):
+                ost = check_all(ctx, of, scenes.with_flags(p, lod_percent=lod, cull=1))
+                assert ost["points_iterated"] > 0
+
+
 @pytest.mark.parametrize("size", [(64, 36), (33, 97), (4096, 4096)])
 def test_image_sizes_and_clipped_windows(ctx, size):
     w, h = size
