@@ -4,12 +4,16 @@
 // below is spelled __fmaf_rn/__fma_rn), default correctly-rounded f32 division and sqrt, no fast-math.
 //
 // Kernels
-//   k_lod_prepass   one thread per batch: frustum cull + LOD (render.cu:333-379) -> lod word per batch + stats
+//   k_lod_prepass   eight lanes per batch: frustum cull + LOD (render.cu:333-379) -> lod word per batch + stats, the dense lists
+//                   of the batches to draw (ballot + prefix compaction), and the LDS framebuffer windows of each (plan_windows)
 //   k_transcode     once per loaded batch: the reference's lockstep walk over the cluster-interleaved stream
-//                   (render.cu:404-451), recording per chain the words it receives -> lane-major stream
+//                   (render.cu:404-451), recording per chain the words it receives -> lane-major stream, 40-bit point windows,
+//                   packed decoder table, colour blocks in segment-major order
+//   k_bounds        once per loaded batch: where the batch's chains fall apart into spatial clusters (runs of chains + boxes)
 //   k_render<MODE>  every frame, one 1024-thread workgroup per batch, one chain per lane: decodes the chain of
-//                   <= 64 points from its own word sequence with the batch's decoder table in LDS, then projects
-//                   and scatters every point (render.cu:383-540, huffman_hqs/depth.cu, huffman_hqs/render.cu)
+//                   <= 64 points from its own bits with the batch's decoder table in LDS, then projects
+//                   and scatters every point (render.cu:383-540, huffman_hqs/depth.cu, huffman_hqs/render.cu; MODE 3: the
+//                   colour pass over BC7 mode-6 colours)
 //   k_las_*         the 10-10-10 method (modules/compute_loop_las_cuda)
 //   k_resolve_*     framebuffer -> RGBA8 (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
 //   k_merge_* / k_flip_sign  multi-GPU partial-framebuffer merges
@@ -435,19 +439,19 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
 // decode + rasterize: one workgroup per batch, one chain per lane (lanes are independent after k_transcode)
 //
 // Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
-//   s_table  16 KiB  decoder table packed to one dword per key: slow<<31 | (value + 2^20)<<10 | wide<<9 | escape<<8 | len
-//                    (an in-table value outside +-2^20 is flagged `wide` and re-read from global memory)
-//   s_dyn    60 KiB  shared per batch (see DYN_LDS_BYTES above) between
+//   s_table  16 KiB  decoder table packed to one dword per key (TE_* above): value << 10 | wide << 9 | escape << 8 | len
+//                    (an in-table value outside +-2^21 is flagged `wide` and re-read from global memory)
+//   s_dyn    60 KiB  (or 140 KiB) shared per batch (see DYN_LDS_BYTES above) between
 //   s_esc            the escape ("separate") words of the batch, bulk-loaded coalesced up front (batches with
 //                    more than ESC_POOL_WORDS escapes read the ones past the pool from global memory), and
-//   s_win            the framebuffer words of the batch's screen rectangle (k_lod_prepass): the depth pre-read
-//                    and the atomicMin of every point that lands inside run on LDS (ds_read_b64 / ds_min_u64);
-//                    at the end the rectangle is merged into the global framebuffer with one row-coalesced
-//                    atomicMin per improved pixel. min is associative, so the result is the same u64 per pixel;
-//                    what changes is the number of global atomics: one per touched pixel and batch instead of
-//                    one per new per-pixel minimum.
-//   registers        the point's 64-bit window + the next two (LAYOUT_POINT_WINDOWS), or three words of the chain's own
-//                    sequence + two requested a point ahead (LAYOUT_WORDS; see the word window below)
+//   s_win            the framebuffer words of the batch's screen rectangle -- or of one rectangle per run of chains
+//                    (WinPlan, k_lod_prepass): they start empty, the depth pre-read and the atomicMin of every point that
+//                    lands inside run on LDS (ds_read_b64 / ds_min_u64); at the end the windows are merged into the global
+//                    framebuffer with one row-coalesced atomicMin per pixel a point reached and improved. min is
+//                    associative, so the result is the same u64 per pixel; what changes is the number of global atomics:
+//                    one per touched pixel and batch instead of one per new per-pixel minimum.
+//   registers        the point's 40-bit window + the next one + the one in flight (LAYOUT_POINT_WINDOWS), or three words of
+//                    the chain's own sequence + two requested a point ahead (LAYOUT_WORDS; see the word window below)
 // Global loads left in the loop are consumed at least one iteration after they are issued.
 // ------------------------------------------------------------------------------------------------
 // BC1 block -> its four palette colours (render.cu:31-62, always 4-colour mode), one register per channel: byte k of
