@@ -194,3 +194,43 @@ def test_render_cli_reports_a_damaged_file_instead_of_terminating(tmp_path, dama
     assert res.returncode == 1 and "pcr_render:" in res.stderr and "terminate" not in res.stderr
     assert ("record size" in res.stderr) or ("exceed the file" in res.stderr) or ("no HIP device" in res.stderr and damage == "truncated") \
         or "Renderer" in res.stderr or "pcr_create" in res.stderr
+
+
+@pytest.mark.gpu
+def test_bc7_file_through_the_cpp_tools(tmp_path):
+    """`pcr_preprocess --bc7` writes what a reference built with COLOR_COMPRESSION == 7 writes (16 colour bytes per 16 points);
+    pcr_render draws it with the HQS method like the oracle and refuses the basic method."""
+    build.build_tools()
+    rng = np.random.default_rng(5)
+    n = 140_000
+    x = rng.integers(0, 400000, n).astype(np.int32); y = rng.integers(0, 300000, n).astype(np.int32)
+    z = (1000 * np.sin(x / 40000.0) + rng.integers(-20, 20, n)).astype(np.int32)
+    r = ((x // 1600) % 256).astype(np.uint16); g = ((y // 1200) % 256).astype(np.uint16); b = rng.integers(0, 256, n).astype(np.uint16)
+    las = write_las(tmp_path / "in.las", x, y, z, r, g, b)
+    out = tmp_path / "bc7.huffman"
+    assert subprocess.run([build.PREPROCESS_BIN, str(tmp_path / "in.las"), str(out), "1", "2", "--bc7"], stdout=subprocess.PIPE).returncode == 0
+    color = r.astype(np.uint32) | (g.astype(np.uint32) << 8) | (b.astype(np.uint32) << 16)
+    image, _ = P.encode_points(x, y, z, color, las, morton_sort=True, nthreads=2, bc7=True)
+    assert out.read_bytes() == bytes(image.view())
+    of = oracle.OracleFile(out.read_bytes())
+    assert of.s.color_format == 7
+    W, H = 480, 270
+    cam = ["-0.15", "-0.57", "700", "210", "170", "30"]
+    res = subprocess.run([build.RENDER_BIN, str(out), "--method", "huffman_hqs", "--size", f"{W}x{H}", "--camera", *cam,
+                          "--dump-fb", str(tmp_path / "fb.u64"), "--dump-rgba", str(tmp_path / "o.ppm")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    p = P.camera_orbit(-0.15, -0.57, 700.0, (210.0, 170.0, 30.0), W, H)
+    hfb, _ = of.render_hqs_depth(p)
+    assert np.array_equal(np.fromfile(tmp_path / "fb.u64", np.uint64), hfb[:W * H])
+    rg, ba, _ = of.render_hqs_color(p, hfb)
+    want = oracle.resolve_hqs(p, hfb, rg, ba).reshape(H, W)[::-1]                 # the PPM starts with the top row
+    ppm = (tmp_path / "o.ppm").read_bytes()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert ppm.startswith(head)
+    got = np.frombuffer(ppm, np.uint8, W * H * 3, len(head)).reshape(H, W, 3).astype(np.uint32)
+    assert np.array_equal(got[..., 0] | (got[..., 1] << 8) | (got[..., 2] << 16), want & 0xFFFFFF)
+    assert int((hfb[:W * H] != 2 ** 64 - 1).sum()) > 2000
+    res = subprocess.run([build.RENDER_BIN, str(out), "--method", "huffman_mem_iter_cuda", "--size", f"{W}x{H}", "--camera", *cam],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode != 0 and "BC7" in res.stderr
