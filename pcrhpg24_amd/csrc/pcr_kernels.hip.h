@@ -1125,6 +1125,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
     uint32_t toff_ahead = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
     uint32_t e_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff_ahead);
+    // (point windows: the second symbol's entry of the point ahead as well, see the loop)
+    uint32_t sft_ahead = SFT0 - e_ahead;                    // :439 (the whole entry: byte 0 is the length)
+    uint32_t toff1_ahead = ((uint32_t)(bits >> 32) >> (sft_ahead & 31u)) & 0x3FFCu;
+    uint32_t e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
 
     // ---- the point loop ---------------------------------------------------------------------------------------------------------
     // A wave issues in order and the decode is a chain of LDS round trips (table entry -> length -> next key -> next
@@ -1219,17 +1223,16 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
         uint32_t d0, d1, d2;
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {
-            // The first symbol's key is the top of the point's own window: its entry was requested a whole point ago, and the
-            // one of point i+1 (whose window is already in registers) is requested now. Left on the dependent chain are two LDS
-            // round trips per point: entry 0 -> length -> key 1 -> entry 1 -> length -> key 2 -> entry 2. The second symbol
-            // starts and ends inside the window's first 32 bits (a 32-bit shift: the hardware takes the count modulo 32, and
-            // SFT0 - 32 = 18), the third may reach into the low plane's byte.
-            const uint32_t e0 = e_ahead, toff0 = toff_ahead;
+            // The first symbol's key is the top of the point's own window: its entry was requested a whole point ago (the one of
+            // point i+1, whose window is already in registers, is requested now). The second symbol's entry was requested before
+            // the point began as well: at the end of the iteration before, as soon as the first entry gave the second key (the
+            // second symbol starts and ends inside the window's first 32 bits: a 32-bit shift, the hardware takes the count
+            // modulo 32 and SFT0 - 32 = 18). Left on the dependent chain of a point: entry 1 -> length -> key 2 -> entry 2, one LDS
+            // round trip (the third symbol may reach into the low plane's byte).
+            const uint32_t e0 = e_ahead, toff0 = toff_ahead, e1 = e1_ahead, toff1 = toff1_ahead;
+            sft = sft_ahead;
             toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
             e_ahead = table_entry(toff_ahead);
-            sft = SFT0 - e0;                                                // :439 (the whole entry: byte 0 is the length)
-            const uint32_t toff1 = ((uint32_t)(bits >> 32) >> (sft & 31u)) & 0x3FFCu;
-            const uint32_t e1 = table_entry(toff1);
             d0 = entry_value(e0, toff0);                                    // :430
             // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
             // word has been in flight since the end of the last iteration
@@ -1347,6 +1350,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #else
         project_request();
 #endif
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) {       // `bits` is the next point's window by now, e_ahead its first entry (requested at the top)
+            sft_ahead = SFT0 - e_ahead;
+            toff1_ahead = ((uint32_t)(bits >> 32) >> (sft_ahead & 31u)) & 0x3FFCu;
+            e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
+        }
         if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo << 24; }
 #ifdef PCR_EXP_EXTRA_LOAD
         asm volatile("; extra load consumed %0" :: "v"(extra0));
