@@ -8,13 +8,17 @@
 Workload at N = 1 (BASELINE.json configs[1]): 1e8 synthetic Morton-sorted points, per-batch Huffman-compressed
 (1526 batches), 1920x1080, basic {depth,colour} atomicMin raster, LOD% = 100 and frustum culling off so every point is
 decoded and rasterized, stream resident in HBM in the context's default layout (point windows).
-At N > 1 (configs[3]): 2e9 points in total, chunks sharded contiguously over the ranks (strong scaling over N = 2, 4, 8;
---points P makes it P points per GPU instead), every step ending with the merge of the partial framebuffers over RCCL:
-by default a min-reduce of the u64 frame to the display rank (--merge a2a / allreduce: the other forms).
+At N > 1 (configs[3]): 2e9 points in total (30 518 batches), contiguous BATCH ranges per rank (6 x 3815 + 2 x 3814 at
+N = 8: strong scaling over N = 2, 4, 8; --points P makes it P points per GPU instead), every step ending with the merge of
+the partial framebuffers over RCCL: by default a min-reduce of the u64 frame to the display rank (--merge allreduce /
+sliced: the other forms). `scaling_base` in the line is the SAME 2e9-point stream on one GPU (a stored one-GPU run of this
+bench): the 1e8-point line of N = 1 is another stream (other entropy) and no base for a scaling curve.
 A step = clear + decode/rasterize every loaded batch + (merge) + resolve, inputs resident in HBM (one GPU: the resolve of a
 frame, the clear and the next frame's cull/LOD prepass share one launch, pcr_frame_turn).
 Before the W warm-up steps the frame loop runs for --preroll seconds (not counted as warm-up, not timed): the clocks of a
 fresh box settle in that time, so a 20-step run reports what a 200-step run reports.
+At N = 1 the line also carries `secondary`: the reference-default row (LOD 10 % + culling), the HQS method and
+4096x4096 with culling (configs[2], configs[4]'s one-GPU half), 20 steps each on the same resident stream.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -29,10 +33,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CHUNK = 6553600
+CHUNK = 6553600                    # points per Morton-sorted chunk = 100 batches (src/preprocess.cpp:1194-1200)
+BATCH = 65536
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 POINTS_ONE_GPU = 100_000_000       # BASELINE.json configs[1]
 POINTS_NODE = 2_000_000_000        # BASELINE.json configs[3]: the whole node's stream at N > 1
+SCALING_BASE_FILE = os.path.join("profiles", "scaling_base_2e9_one_gpu.json")
 
 
 def parse_args():
@@ -50,17 +56,18 @@ def parse_args():
     ap.add_argument("--camera", choices=["overview", "closeup"], default="overview")
     ap.add_argument("--layout", choices=["point_windows", "words"], default="point_windows",
                     help="HBM layout of the resident stream = decode variant of the timed steps (pcr_set_stream_layout)")
-    ap.add_argument("--merge", choices=["reduce", "allreduce", "a2a"], default="reduce",
+    ap.add_argument("--merge", choices=["reduce", "allreduce", "sliced", "sliced_p2p"], default="reduce",
                     help="multi-GPU exchange of the basic method: min-reduce the partial framebuffers to rank 0 (the display "
-                         "rank), all-reduce them, or all-to-all slices + local min/resolve + all-gather of the image")
-    ap.add_argument("--pipelined", action="store_true", help="N > 1: merge of frame k on a second stream under the render of frame k+1")
-    ap.add_argument("--transport", choices=["auto", "rccl", "torch"], default="auto",
-                    help="N > 1: who calls RCCL. rccl = the C++ layer (include/pcr_dist.h: ncclUint64 min in place on the context's "
-                         "stream); torch = torch.distributed collectives on torch-owned int64 frames; auto = rccl after one frame of "
-                         "each has produced the same merged framebuffer on rank 0, torch otherwise")
+                         "rank), all-reduce them, or cut the frame into N slices: reduce-scatter (sliced_p2p, C++ layer only: all-to-all "
+                         "+ local min), resolve of the own slice, gather of the image")
+    ap.add_argument("--transport", choices=["torch", "rccl", "auto"], default="torch",
+                    help="N > 1: who calls RCCL. torch (default until the C++ layer has met a peer on hardware): torch.distributed "
+                         "collectives on torch-owned int64 frames; rccl = the C++ layer (include/pcr_dist.h: ncclUint64 min in place on "
+                         "the context's stream); auto = rccl after one frame of each has produced the same merged image on rank 0, torch otherwise")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the second pass with the other stream layout")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (LOD 10 % + cull, HQS, 4096x4096 + cull)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="keep the per-launch kernel events out of the timed steps (A/B of their overhead)")
     ap.add_argument("--cpu-sample-batches", type=int, default=0, help="0 = automatic (bounded)")
@@ -92,6 +99,21 @@ def load_traffic(P, args):
     return t.get("hbm_bytes_per_launch", {}), "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, kernel %s; not measured by this run)" % ver
 
 
+def scaling_base(P, total_points, args):
+    """The same stream on ONE GPU, from a stored run of this bench (`python bench.py --points 2000000000 > profiles/...`):
+    what a 1 -> N curve of the N > 1 lines has to be set against."""
+    path = os.path.join(ROOT, SCALING_BASE_FILE)
+    try:
+        d = json.load(open(path))
+        c = d["config"]
+        if d["n_gpus"] != 1 or c["points_per_step"] < total_points or (args.width, args.height) != (1920, 1080) or args.method != "basic":
+            return {"value": None, "why": "%s holds another workload" % SCALING_BASE_FILE}
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "n_gpus": 1, "points_per_step": c["points_per_step"],
+                "kernel_version": d["roofline"]["kernel_version"], "this_kernel_version": P.kernel_version(), "source": SCALING_BASE_FILE}
+    except Exception as e:
+        return {"value": None, "why": "%s unreadable: %s" % (SCALING_BASE_FILE, e)}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -121,19 +143,24 @@ def main():
 
     nthreads = args.threads or min(os.cpu_count() or 8, 16)
 
-    # ---- synthetic input: this rank's contiguous range of chunks of the global scene -------------------------
+    # ---- synthetic input: this rank's contiguous range of BATCHES of the global scene ----------
     fixed_total = args.points == 0 and world > 1           # BASELINE configs[3]: 2e9 points over the node, whatever N is
     if args.points == 0:
         args.points = POINTS_ONE_GPU if world == 1 else POINTS_NODE // world
     total_points = POINTS_NODE if fixed_total else args.points * world
     nchunks = -(-total_points // CHUNK)
-    c0, cn = pdist.shard_range(nchunks, world, rank)
-    first = c0 * CHUNK
-    count = min(total_points, (c0 + cn) * CHUNK) - first
+    nb_total = (nchunks - 1) * (CHUNK // BATCH) + -(-(total_points - (nchunks - 1) * CHUNK) // BATCH)    # every chunk is padded to whole batches
+    first_b, count_b = pdist.shard_range(nb_total, world, rank)
+    # the chunks that hold my batches and the batch that follows them (its head words close the shard: SURVEY B.4)
+    c0 = first_b // (CHUNK // BATCH)
+    c1 = min(nchunks, -(-(first_b + count_b + 1) // (CHUNK // BATCH)))
+    gen_first = c0 * CHUNK
     t0 = time.time()
-    image, enc = P.synth_encode(total_points, args.seed, first, count, CHUNK, nthreads)
+    image, enc = P.synth_encode(total_points, args.seed, gen_first, min(total_points, c1 * CHUNK) - gen_first, CHUNK, nthreads)
     t_gen = time.time() - t0
     hf = P.HuffmanFile(image)
+    local_first = first_b - c0 * (CHUNK // BATCH)
+    has_follower = first_b + count_b < nb_total
 
     ctx = P.Context(local_rank)
     ctx.set_image_size(args.width, args.height)
@@ -148,25 +175,37 @@ def main():
             ctx.stream_unload()
         ctx.set_stream_layout(LAYOUTS[layout])
         t0 = time.time()
-        ctx.stream_begin(hf.header(), 0)
-        for b0 in range(0, hf.numBatches, 100):
-            ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
-        if world > 1:
-            # shard boundary: the words that follow this shard in the global stream
-            nxt = pdist.exchange_shard_heads(*hf.head_words(0), dev)
-            if nxt is not None:
-                ctx.upload_tail(*nxt)
+        ctx.stream_begin(hf.header(local_first, count_b), first_b)
+        for b0 in range(0, count_b, 100):
+            ctx.upload_batches(b0, [hf.blob(local_first + b) for b in range(b0, min(b0 + 100, count_b))])
+        if has_follower:
+            ctx.upload_tail(*hf.head_words(local_first + count_b))
         ctx.synchronize()
         return time.time() - t0
 
     t_load = load(args.layout)
 
-    frame, pipe, native = None, None, None
+    frame, native = None, None
     transport, transport_check = ("single GPU", None)
+
+    def single_gpu_step(method, q):
+        # One GPU: the steady frame loop is two launches per frame -- k_render (twice for HQS), then pcr_frame_turn = the
+        # reference's RESOLVE + CLEAR (huffman_hqs.h:240-270) fused with the next frame's cull/LOD prepass. Same work as
+        # clear + render + resolve, rotated: the loop is primed with one pcr_frame_begin (timed_run does it).
+        if method == "basic":
+            def step():
+                ctx.render_basic(q)
+                ctx.frame_turn(q, q)
+        else:
+            def step():
+                ctx.render_hqs_depth(q)
+                ctx.render_hqs_color(q)
+                ctx.frame_turn(q, q, hqs=True)
+        return step
 
     def torch_step_setup():
         """Frames owned by torch (int64-mergeable), collectives through torch.distributed, everything on torch's current stream."""
-        fr = pdist.SlicedFrame(ctx, args.width, args.height, dev, world) if (args.merge == "a2a" and args.method == "basic") \
+        fr = pdist.SlicedFrame(ctx, args.width, args.height, dev, world) if (args.merge == "sliced" and args.method == "basic") \
             else pdist.DeviceFrame(ctx, args.width, args.height, dev)
         fr.bind()
         ctx.clear()
@@ -174,23 +213,25 @@ def main():
              (lambda: pdist.render_hqs_sharded(ctx, fr, p, world, merge=args.merge))
         return fr, st
 
-    if use_dist and args.method == "basic" and args.pipelined:
-        pipe = pdist.PipelinedBasicRenderer(ctx, args.width, args.height, dev, merge=args.merge)   # merge of frame k overlaps render k+1
-        step = lambda: pipe.step(p)
-        transport = "torch.distributed (pipelined)"
-    elif use_dist:
+    def image_hash():
         import hashlib
-        import numpy as np
-        want_native = args.transport in ("auto", "rccl") and args.merge != "a2a"
+        return hashlib.sha256(ctx.read_rgba().tobytes()).hexdigest() if rank == 0 else ""
+
+    prime = not use_dist
+    if use_dist:
+        if args.merge == "sliced_p2p" and args.transport == "torch":
+            raise SystemExit("--merge sliced_p2p is a form of the C++ layer: use --transport rccl")
+        want_native = args.transport in ("auto", "rccl")
         root = -1 if args.merge == "allreduce" else 0
         native_hash = None
         if want_native:
             try:
                 native = pdist.NativeDist(ctx, rank, world, dev)
+                native.set_exchange({"reduce": "reduce", "allreduce": "reduce"}.get(args.merge, args.merge))
                 native_step = (lambda: native.frame_basic(p, root)) if args.method == "basic" else (lambda: native.frame_hqs(p, root))
                 native_step()
                 ctx.synchronize()
-                native_hash = hashlib.sha256(ctx.read_framebuffer(full=True).tobytes()).hexdigest() if rank == 0 else ""
+                native_hash = image_hash()
             except Exception as e:                       # RCCL not loadable / communicator refused: the torch transport still runs
                 native, transport_check = None, "C++ RCCL layer unavailable: %s" % e
         ok = torch.tensor([1 if native is not None else 0], device=dev)
@@ -199,56 +240,45 @@ def main():
             if native is not None:
                 native.close()
             native = None
-        if native is not None and args.transport == "auto":
+        if native is not None and args.transport == "auto" and args.merge != "sliced_p2p":
             frame, tstep = torch_step_setup()
             tstep()
             ctx.synchronize(); torch.cuda.synchronize()
             same = torch.tensor([1], device=dev)
             if rank == 0:
-                torch_hash = hashlib.sha256(ctx.read_framebuffer(full=True).tobytes()).hexdigest()
-                same[0] = 1 if torch_hash == native_hash else 0
+                import hashlib
+                timg = frame.image().cpu().numpy()[:args.width * args.height] if isinstance(frame, pdist.SlicedFrame) else ctx.read_rgba()
+                same[0] = 1 if hashlib.sha256(timg.tobytes()).hexdigest() == native_hash else 0
             dist.broadcast(same, 0)
             frame.release(); frame = None
             if int(same.item()):
-                transport_check = "one frame merged by the C++ layer and one merged through torch.distributed: identical u64 framebuffers on rank 0"
+                transport_check = "one frame merged by the C++ layer and one merged through torch.distributed: identical images on rank 0"
             else:
-                transport_check = "C++ layer and torch.distributed disagreed on rank 0's merged framebuffer: torch transport used"
+                transport_check = "C++ layer and torch.distributed disagreed on rank 0's merged image: torch transport used"
                 native.close(); native = None
         if native is not None:
             step = (lambda: native.step_basic(p, root)) if args.method == "basic" else native_step
-            transport = "RCCL from C++ (include/pcr_dist.h: ncclUint64 %s, in place on the context's stream)" % ("min" if args.method == "basic" else "min / sum")
+            prime = args.method == "basic"
+            transport = "RCCL from C++ (include/pcr_dist.h, exchange %s, in place on the context's stream)" % native.set_exchange(
+                {"reduce": "reduce", "allreduce": "reduce"}.get(args.merge, args.merge))
         else:
             frame, step = torch_step_setup()
             transport = "torch.distributed (int64-mergeable frames)"
     else:
-        # One GPU: the steady frame loop is two launches per frame -- k_render (twice for HQS), then pcr_frame_turn = the
-        # reference's RESOLVE + CLEAR (huffman_hqs.h:240-270) fused with the next frame's cull/LOD prepass. Same work as
-        # clear + render + resolve, rotated: the loop is primed with one pcr_frame_begin (timed_run does it).
-        if args.method == "basic":
-            def step():
-                ctx.render_basic(p)
-                ctx.frame_turn(p, p)
-        else:
-            def step():
-                ctx.render_hqs_depth(p)
-                ctx.render_hqs_color(p)
-                ctx.frame_turn(p, p, hqs=True)
+        step = single_gpu_step(args.method, p)
 
     def fence():
-        if pipe is not None:
-            pipe.finish()
         ctx.synchronize()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    launches_per_step = 1 if args.method == "basic" else 2
-
-    def timed_run(steps, warmup, preroll_s, kernel_events=True):
+    def timed_run(step, method, q, steps, warmup, preroll_s, kernel_events=True, prime=True):
         """(elapsed seconds of `steps` steps between fences, average k_render ms, launches timed, first-frame ms)."""
-        if not use_dist or (native is not None and args.method == "basic"):
-            ctx.frame_begin(p, hqs=args.method == "hqs")     # primes the turn-based loops (clear + prepass); untimed
+        launches_per_step = 1 if method == "basic" else 2
+        if prime:
+            ctx.frame_begin(q, hqs=method == "hqs")      # primes the turn-based loops (clear + prepass); untimed
         fence()
         t0 = time.perf_counter()
         step()
@@ -257,11 +287,9 @@ def main():
         # clock pre-roll: frames until the wall clock says so (every rank runs the same count: rank 0 decides)
         if preroll_s > 0:
             t0 = time.perf_counter()
-            n = 0
             while True:
                 for _ in range(50):
                     step()
-                n += 50
                 ctx.synchronize()
                 go_on = torch.tensor([1 if time.perf_counter() - t0 < preroll_s else 0], device=dev)
                 if use_dist:
@@ -288,17 +316,17 @@ def main():
         ctx.kernel_timing(False)
         return elapsed, kernel_ms, launches, first_ms
 
-    elapsed, kernel_ms, kernel_launches, first_frame_ms = timed_run(args.steps, args.warmup, args.preroll, not args.no_kernel_events)
+    elapsed, kernel_ms, kernel_launches, first_frame_ms = timed_run(step, args.method, p, args.steps, args.warmup, args.preroll,
+                                                                    not args.no_kernel_events, prime)
 
     # distribution of single steps (after the timed region, each step between its own event pair and a sync: launch gaps
     # included, pipelining across steps excluded)
     step_ms = []
-    if pipe is None:
-        for _ in range(48):
-            ctx.timing_begin()
-            step()
-            step_ms.append(ctx.timing_end())
-        fence()
+    for _ in range(48):
+        ctx.timing_begin()
+        step()
+        step_ms.append(ctx.timing_end())
+    fence()
 
     st = ctx.stats()            # counters of the last render launch (per rank)
     pts = torch.tensor([st["points_iterated"]], dtype=torch.float64, device=dev)
@@ -314,7 +342,10 @@ def main():
     # ---- dominant kernel: per-launch HIP event pairs recorded inside pcr_render_* on the context's stream, around
     # k_render only, during the timed steps above (pcr_kernel_timing_*; a stride keeps it to <=64 pairs spread over the
     # whole timed region, since an event pair costs ~5 us of stream time) ---------------------------------------------
-    alg_bytes = ctx.algorithmic_bytes                      # decode-pass bytes of this rank's shard (SURVEY 8d B_dec * points)
+    # decode-pass bytes of what this rank's launch drew (SURVEY 8d B_dec x points): the whole shard at LOD 100 % without
+    # culling; with a level of detail or culling only the batches drawn, and of their words the share the LOD decodes
+    full_frame = args.lod >= 100 and not args.cull
+    alg_bytes = ctx.algorithmic_bytes if full_frame else ctx.last_frame_algorithmic_bytes
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     traffic_by_variant, traffic_source = load_traffic(P, args) if world == 1 else ({}, "not quoted for N > 1")
     resident_main = ctx.resident_bytes
@@ -327,6 +358,8 @@ def main():
                                   "frac_of_read": round(achieved / hbm_read, 5) if hbm_read else None},
                 "kernel": kernel_name, "kernel_version": P.kernel_version(),
                 "kernel_ms": round(kernel_ms, 4), "kernel_launches_timed": kernel_launches, "algorithmic_bytes": alg_bytes,
+                "algorithmic_bytes_how": "every byte of the compressed stream once (pcr_stream_algorithmic_bytes)" if full_frame else
+                                         "drawn batches only, words by the decoded share npr/64 of each chain (pcr_last_frame_algorithmic_bytes)",
                 "bytes_per_point": round(alg_bytes / max(1, st["points_iterated"]), 4)}
 
     def variant_record(layout, ms_step, k_ms, resident):
@@ -334,7 +367,7 @@ def main():
         return {"ms_per_step": round(ms_step, 4), "kernel_ms": round(k_ms, 4),
                 "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "Mpoints_per_s": round(points_per_step / (ms_step * 1e-3) / 1e6, 1),
-                "resident_bytes_per_point": round(resident / max(1, hf.numPoints), 3),
+                "resident_bytes_per_point": round(resident / max(1, count_b * BATCH), 3),
                 "hbm_bytes_read_per_point": round(tr / max(1, st["points_iterated"]), 3) if tr else None}
 
     variants = {args.layout: variant_record(args.layout, ms_per_step, kernel_ms, resident_main)}
@@ -372,18 +405,47 @@ def main():
             a, b = of.count_depth_ties(p, ofb)
             ties = {"depth_tie_pixels": a, "depth_tie_pixels_other_colour": b}
 
+    # ---- secondary rows, same resident stream (N == 1 only): 20 steps each --------------------------------------------------
+    secondary = None
+    if world == 1 and not use_dist and not args.no_secondary:
+        secondary = {}
+        rows = (("lod10_cull1", "basic", args.width, args.height, 10, 1, "LOD 10 % + frustum culling: the reference's defaults (include/Debug.h:21-23)"),
+                ("hqs", "hqs", args.width, args.height, 100, 0, "HQS two-pass (BASELINE configs[2])"),
+                ("4096_cull1", "basic", 4096, 4096, 100, 1, "4096x4096 with culling (BASELINE configs[4], one GPU's view of it)"))
+        for name, method, w, h, lod, cull, what in rows:
+            if (w, h) != (args.width, args.height):
+                ctx.set_image_size(w, h)
+            q = camera(P, args.camera, w, h)
+            q.lod_percent, q.enable_frustum_culling = lod, cull
+            s_step = single_gpu_step(method, q)
+            e, k_ms, _, _ = timed_run(s_step, method, q, 20, 3, 0.2)
+            sst = ctx.stats()
+            whole = lod >= 100 and sst["batches_culled"] == 0
+            ab = ctx.algorithmic_bytes if whole else ctx.last_frame_algorithmic_bytes
+            secondary[name] = {"what": what, "method": method, "width": w, "height": h, "lod_percent": lod, "cull": cull, "steps": 20,
+                               "ms_per_step": round(1e3 * e / 20, 4), "points_per_step": int(sst["points_iterated"]),
+                               "Mpoints_per_s": round(sst["points_iterated"] / (e / 20) / 1e6, 1),
+                               "batches_culled": int(sst["batches_culled"]),
+                               "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": 1 if method == "basic" else 2,
+                               "algorithmic_bytes": ab, "frac": round(ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else None}
+            if (w, h) != (args.width, args.height):
+                ctx.set_image_size(args.width, args.height)
+
     # ---- the other layout, same stream, same camera: a shorter second pass (N == 1 only) ---------------------------
     if world == 1 and not use_dist and not args.no_variants:
         other = "words" if args.layout == "point_windows" else "point_windows"
         load(other)
-        e2, k2, _, _ = timed_run(min(args.steps, 100), args.warmup, min(args.preroll, 0.3))
-        variants[other] = variant_record(other, 1e3 * e2 / min(args.steps, 100), k2, ctx.resident_bytes)
+        n2 = min(args.steps, 100)
+        e2, k2, _, _ = timed_run(single_gpu_step(args.method, p), args.method, p, n2, args.warmup, min(args.preroll, 0.3))
+        variants[other] = variant_record(other, 1e3 * e2 / n2, k2, ctx.resident_bytes)
 
     if args.method == "hqs":
-        merge_desc = "min all-reduce of the depth + sum %s of the colour sums" % ("all-reduce" if args.merge == "allreduce" else "reduce to rank 0")
+        merge_desc = "min all-reduce of the depth + sum %s of the colour sums" % (
+            "all-reduce" if args.merge == "allreduce" else "reduce-scatter, resolve per slice, gather of the image" if args.merge.startswith("sliced") and native is not None else "reduce to rank 0")
     else:
         merge_desc = {"reduce": "min reduce to rank 0", "allreduce": "min all-reduce",
-                      "a2a": "all-to-all of frame slices + local min/resolve + all-gather of the image"}[args.merge]
+                      "sliced": "frame slices: reduce-scatter (torch transport: all-to-all + local min), resolve of the own slice, gather of the image",
+                      "sliced_p2p": "frame slices: all-to-all + local min, resolve of the own slice, gather of the image"}[args.merge]
     if rank == 0:
         layout_desc = {"point_windows": "stream resident as per-point 40-bit windows (5 B/point), decode variant point_windows",
                        "words": "stream resident as lane-major packed words (~3 B/point read), decode variant words"}[args.layout]
@@ -396,11 +458,11 @@ def main():
                                    % (total_points if fixed_total else args.points, "in total over the node" if fixed_total else "per GPU",
                                       args.width, args.height,
                                       "basic atomicMin raster" if args.method == "basic" else "HQS two-pass", args.camera, args.lod, args.cull, layout_desc),
-                       "points_per_step": int(points_per_step), "batches_per_gpu": hf.numBatches,
+                       "points_per_step": int(points_per_step), "batches_per_gpu": count_b, "batches_total": nb_total,
                        "batches_culled_rank0": int(st["batches_culled"]),
                        "encoded_bits_per_point": round(8.0 * enc["encoded_bytes"] / enc["num_points"], 3),
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
-                       "parallelism": ("batch-sharded x%d + RCCL %s%s" % (world, merge_desc, " overlapped with the next frame" if pipe else "")) if use_dist else "single GPU",
+                       "parallelism": ("contiguous batch shards x%d + RCCL %s" % (world, merge_desc)) if use_dist else "single GPU",
                        "transport": transport, "transport_check": transport_check,
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "preroll_s": args.preroll,
                        "first_frame_ms": round(first_frame_ms, 3)},
@@ -408,14 +470,14 @@ def main():
                         "n": len(step_ms), "how": "single steps after the timed region, one HIP event pair and one sync each"} if step_ms else None,
             "roofline": roofline,
             "variants": variants,
+            "secondary": secondary,
+            "scaling_base": scaling_base(P, total_points, args) if fixed_total else None,
             "cpu_baseline": cpu_baseline,
             "parity_full_size": parity,
             "depth_ties": ties,
         }
         print(json.dumps(out), flush=True)
 
-    if pipe is not None:
-        pipe.release()
     if frame is not None:
         frame.release()
     if native is not None:

@@ -13,6 +13,13 @@
  *     HQS   :  depth pass -> ncclAllReduce(fb, ncclUint64, ncclMin)     every rank tests against the GLOBAL depth
  *              colour pass -> ncclReduce(RG | BA, ncclUint64, ncclSum)  packed 2 x 32-bit sums, no carry between halves
  * in place, on the context's own stream (stream order against the render kernels, no host synchronisation).
+ * The sliced exchange (large frames: 4096 x 4096 is 134 MB, which a reduce moves whole into rank 0): the frame is cut into
+ * N equal slices, rank r ends up with the merged slice r, resolves it, and only the RGBA8 pixels travel on --
+ *     basic :  ncclReduceScatter(fb, ncclUint64, ncclMin) -> resolve of the own slice -> ncclGather / ncclAllGather(rgba)
+ *              (or, PCR_DIST_EXCHANGE_SLICED_P2P: ncclAllToAll of the slices + a local min: one slice per xGMI link, whatever
+ *               algorithm RCCL would pick for the collective)
+ *     HQS   :  depth all-reduce as above, then ncclReduceScatter(RG | BA, ncclSum) -> resolve of the own slice -> gather
+ * Per link that is 1/N of the frame + 1/N of the image instead of the whole frame (DESIGN.md 6 has the byte counts).
  * RCCL's native unsigned 64-bit min is used, so the framebuffer keeps its all-ones "empty" word (the torch transport of
  * pcrhpg24_amd/dist.py needs pcr_set_int64_mergeable because torch exposes signed int64 only).
  *
@@ -60,9 +67,38 @@ int pcr_dist_group_end(void);
 int pcr_dist_merge_min(pcr_dist *d, int root);          /* fb: u64 min */
 int pcr_dist_merge_sum(pcr_dist *d, int root);          /* RG and BA: u64 sum */
 
-/* Whole frames: clear + shard render + merge (+ resolve on the ranks that hold the result). With one thread driving
- * several ranks, call the *_begin halves for every rank, then the *_merge halves between group_begin/group_end, then the
- * *_finish halves; pcr_dist_frame_basic / _hqs do all three for the one-process-per-GPU case. */
+/* Which exchange the whole-frame calls below use. AUTO (default): REDUCE while a framebuffer is smaller than
+ * PCR_DIST_SLICED_MIN_BYTES or the communicator has one rank, SLICED from there on. pcr_dist_exchange: what AUTO resolves to
+ * for the context's current image size (or the mode that was set). */
+#define PCR_DIST_EXCHANGE_AUTO        0
+#define PCR_DIST_EXCHANGE_REDUCE      1   /* ncclReduce / ncclAllReduce of the whole u64 frame */
+#define PCR_DIST_EXCHANGE_SLICED      2   /* ncclReduceScatter + resolve of the own slice + gather of the RGBA8 image */
+#define PCR_DIST_EXCHANGE_SLICED_P2P  3   /* the same with ncclAllToAll + a local min instead of the reduce-scatter (basic method) */
+#define PCR_DIST_SLICED_MIN_BYTES     (64u << 20)
+int pcr_dist_set_exchange(pcr_dist *d, int mode);
+int pcr_dist_exchange(const pcr_dist *d);
+/* Slice `rank` of a frame of `elems` words cut into `world` slices: [first, first + count), count = ceil(elems / world) rounded
+ * up to an even number of words (16-byte aligned slices), the same for every rank; the last slices reach into the frame's
+ * pad (pcr_framebuffer_capacity). Pure arithmetic (pcrhpg24_amd/dist.py::slice_elems is the same). */
+void pcr_dist_slice_range(size_t elems, int world, int rank, size_t *first, size_t *count);
+/* The sliced merges, in place: afterwards words [first, first + count) of this rank's fb (RG, BA) hold the merged slice, the
+ * rest of the buffer is unspecified. With PCR_DIST_EXCHANGE_SLICED_P2P the merged fb slice is in a scratch buffer of the
+ * communicator instead. pcr_dist_merged_slice returns where it is after the last pcr_dist_merge_min_sliced (device pointer)
+ * and, for the P2P form, enqueues the local min over the received copies -- call it after pcr_dist_group_end when the
+ * merge was issued inside a group. */
+int pcr_dist_merge_min_sliced(pcr_dist *d);
+int pcr_dist_merge_sum_sliced(pcr_dist *d);
+const void *pcr_dist_merged_slice(pcr_dist *d);
+/* Every rank has resolved the pixels of its slice into pcr_device_rgba at the slice's offset; assemble the image on `root`
+ * (ncclGather) or on every rank (PCR_DIST_ALL: ncclAllGather). */
+int pcr_dist_gather_image(pcr_dist *d, int root);
+
+/* Whole frames: clear + shard render + merge (+ resolve where the result ends up), by the exchange that is set. These are
+ * for one process per GPU. With one thread driving several ranks (pcr_dist_create_local) the collectives of the N ranks have to
+ * be issued together instead: pcr_frame_begin / pcr_render_* for every rank, then pcr_dist_group_begin, pcr_dist_merge_* for
+ * every rank, pcr_dist_group_end, then pcr_resolve_* (sliced: pcr_resolve_*_range on the own slice, and pcr_dist_gather_image
+ * inside a second group) -- pcr_render_dist.cpp is that sequence. After a sliced frame no rank holds the whole merged u64
+ * frame; the image (pcr_read_rgba) is complete on root (or on every rank). */
 int pcr_dist_frame_basic(pcr_dist *d, const pcr_render_params *p, int root);
 int pcr_dist_frame_hqs(pcr_dist *d, const pcr_render_params *p, int root);
 /* The basic frame in its steady-state form: render + merge + one launch for resolve, CLEAR and the next frame's prepass

@@ -132,6 +132,11 @@ int pcr_read_rgba(pcr_ctx *ctx, uint32_t *host, size_t n_pixels);               
 void *pcr_get_stream(pcr_ctx *ctx);
 int pcr_get_device(const pcr_ctx *ctx);
 size_t pcr_framebuffer_elems(const pcr_ctx *ctx);
+/* Words each of the three buffers can hold: pcr_framebuffer_elems + PCR_FRAME_PAD_ELEMS for the context's own buffers (the
+ * pad holds the identity of min / sum: a collective over whole slices may include it), pcr_framebuffer_elems while
+ * external buffers are in use. pcr_device_rgba: the RGBA8 image the resolves write (same capacity, in pixels). */
+size_t pcr_framebuffer_capacity(const pcr_ctx *ctx);
+void *pcr_device_rgba(pcr_ctx *ctx);
 void *pcr_device_framebuffer(pcr_ctx *ctx);
 void *pcr_device_rg(pcr_ctx *ctx);
 void *pcr_device_ba(pcr_ctx *ctx);
@@ -151,6 +156,10 @@ int   pcr_flip_sign(pcr_ctx *ctx);
  * on the context's stream. */
 int pcr_merge_min_slices(pcr_ctx *ctx, void *slices, int nslices, size_t slice_elems);
 int pcr_resolve_basic_range(pcr_ctx *ctx, const pcr_render_params *params, const void *fb, size_t count, void *rgba);
+/* The same for the HQS resolve (huffman_hqs/resolve.cu:2-47 depends on the pixel's three words only): `count` pixels of
+ * corresponding ranges of fb / RG / BA. */
+int pcr_resolve_hqs_range(pcr_ctx *ctx, const pcr_render_params *params, const void *fb, const void *rg, const void *ba,
+                          size_t count, void *rgba);
 
 /* Ordering between two streams of the context's device without the system-scope release a default HIP event carries
  * (which writes the L2 back: the 16.6 MB framebuffer the next kernel is about to read). slot in [0, 8). A frame rendered
@@ -248,6 +257,10 @@ int pcr_kernel_timing_read(pcr_ctx *ctx, float *avg_ms, int *launches);
 /* Algorithmic HBM bytes of one render launch over the loaded stream, SURVEY 8d's B_dec x points: every byte of the
  * compressed representation once (encoded + separate + cluster prefix + per batch 160 + 12 288 + 4 096 + 32 768). */
 int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *ctx);
+/* The same for the frame the last render call drew (synchronises): the batches the cull kept, and of each batch's encoded +
+ * escape words the share npr / 64 of the points per chain its level of detail decodes (a chain's prefix; proportional, the
+ * exact prefix lengths are not recorded) + its side data whole. Equals pcr_stream_algorithmic_bytes for LOD 100 %, no culling. */
+int64_t pcr_last_frame_algorithmic_bytes(pcr_ctx *ctx);
 
 #ifdef __cplusplus
 }

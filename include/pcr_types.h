@@ -47,6 +47,10 @@ extern "C" {
 /* Zero words kept behind each pad that no upload ever writes: device loads clamp their index into them. */
 #define PCR_GUARD_WORDS           8
 
+/* u64 words allocated behind each of a context's own framebuffers (and u32 behind its RGBA8 image): room for the frame to
+ * be cut into N equal slices (N <= 128) by the sliced multi-GPU exchange of include/pcr_dist.h. */
+#define PCR_FRAME_PAD_ELEMS       256
+
 #define PCR_BACKGROUND_COLOR      0x00443322u /* resolve.cu:166 */
 
 /* struct GPUBatch (160 bytes) */

@@ -33,6 +33,7 @@ struct pcr_ctx {
     int64_t batches_loaded = 0, points_loaded = 0;
     int64_t enc_ptr = 0, sep_ptr = 0;           // running word offsets (HuffmanLasLoader.h:50-53)
     int64_t enc_words = 0, sep_words = 0;       // allocation sizes in words incl. pads
+    std::vector<int32_t> h_stream_words;        // per uploaded batch: encoded + escape words (pcr_last_frame_algorithmic_bytes)
     pcr_gpu_batch *d_batches = nullptr;
     int32_t *d_start = nullptr;
     uint32_t *d_encoded = nullptr;
@@ -45,7 +46,8 @@ struct pcr_ctx {
     uint8_t *d_colors_t = nullptr;              // segment-major copy k_render reads (StreamView::colors_t)
     size_t color_bytes = 0;                     // per batch: PCR_COLOR_BYTES_PER_BATCH (BC1) or ..._BC7, told by the first record; 0 = not known yet
     uint32_t *d_lod = nullptr;
-    WinPlan *d_win = nullptr;                   // LDS framebuffer windows of the frame's batches (prepass)
+    WinPlan *d_win = nullptr;                   // LDS framebuffer windows of the frame's batches (prepass): two plans of hdr.num_batches
+                                                // entries, slot 0 for 8-byte pixels (basic / HQS depth), slot 1 for the colour pass's 20-byte pixels
     uint32_t *d_batch_runs = nullptr;           // runs of chains and their bounding boxes, RUN_WORDS per batch (k_bounds)
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
     // dense lists of the batches a frame draws, compacted by k_lod_prepass per workgroup (see RenderArgs): d_order[2][order_stride],
@@ -94,7 +96,8 @@ struct pcr_ctx {
     // pcr_frame_begin ran the prepass of the next render call already, for exactly these inputs
     bool prepass_ready = false;
     pcr_render_params prepass_params{};
-    int prepass_variant_hqs = 0, prepass_win_pixel_bytes = 0;
+    int prepass_variant_hqs = 0;
+    unsigned prepass_slots = 0;                 // which of the two window plans that prepass wrote (bit 0: 8-byte pixels, bit 1: 20-byte)
     uint32_t prepass_dyn_lds = 0;
     bool big_lds_ready = false;                 // hipFuncSetAttribute done for the 140 KiB launches
     int64_t prepass_batches = 0;
@@ -113,6 +116,7 @@ struct pcr_ctx {
     // method (framebuffers)
     int width = 0, height = 0;
     size_t fb_elems = 0;
+    size_t fb_alloc = 0;                        // elements of each own buffer: fb_elems + PCR_FRAME_PAD_ELEMS (pad: fb all ones, RG/BA/rgba zero, written once)
     uint64_t *own_fb = nullptr, *own_rg = nullptr, *own_ba = nullptr;
     uint64_t *fb = nullptr, *rg = nullptr, *ba = nullptr;
     uint32_t *d_rgba = nullptr;
@@ -177,6 +181,7 @@ void free_stream_buffers(pcr_ctx *c)
     c->stream_open = false; c->batches_loaded = c->points_loaded = 0; c->prepass_ready = false;
     c->finalized = false; c->lane_words_scratch = false; c->stream_bytes = 0; c->color_bytes = 0;
     c->enc_ptr = c->sep_ptr = 0; c->enc_words = c->sep_words = 0;
+    c->h_stream_words.clear();
 }
 
 void free_las_buffers(pcr_ctx *c)
@@ -189,7 +194,7 @@ void free_las_buffers(pcr_ctx *c)
 void free_frame_buffers(pcr_ctx *c)
 {
     dfree(c->own_fb); dfree(c->own_rg); dfree(c->own_ba); dfree(c->d_rgba);
-    c->fb = c->rg = c->ba = nullptr; c->fb_elems = 0; c->width = c->height = 0;
+    c->fb = c->rg = c->ba = nullptr; c->fb_elems = 0; c->fb_alloc = 0; c->width = c->height = 0;
 }
 
 template <class T> int dalloc_zero(pcr_ctx *c, T *&p, size_t count, size_t *account = nullptr)
@@ -240,7 +245,7 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.p = *p;
     a.s = make_stream_view(c);
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
-    a.lod = c->d_lod; a.win = c->d_win; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
+    a.lod = c->d_lod; a.win = c->d_win; a.win_hqs = nullptr; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
     a.order = c->d_order;
     a.chunk_count = c->d_chunk_count;
     // chunks of the batches this frame draws (the prepass of the frame covered exactly these)
@@ -339,20 +344,35 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
     if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
     maybe_finalize(c);
-    const int win_pixel_bytes = (MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7) ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
+    constexpr bool color_pass = MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7;
+    const int win_pixel_bytes = color_pass ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
+    const unsigned my_slot = color_pass ? 2u : 1u;
     const int variant_hqs = MODE != MODE_BASIC;
     const uint32_t dyn_lds = frame_dyn_lds(c, nB);
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
-                              c->prepass_win_pixel_bytes == win_pixel_bytes && c->prepass_dyn_lds == dyn_lds &&
+                              (c->prepass_slots & my_slot) && c->prepass_dyn_lds == dyn_lds &&
                               std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
     c->prepass_ready = false;
     RenderArgs a = make_args(c, p, variant_hqs);
+    WinPlan *const plan_slot[2] = { c->d_win, c->d_win + c->hdr.num_batches };
+    a.win = plan_slot[color_pass ? 1 : 0];
     a.win_pixel_bytes = win_pixel_bytes;
     a.dyn_lds_bytes = dyn_lds;
     if (dyn_lds > (uint32_t)DYN_LDS_BYTES && (rc = enable_big_lds(c))) return rc;
+    unsigned slots = c->prepass_slots;
     if (!have_prepass) {
+        // the depth pass's prepass writes the colour pass's window plan as well: cull, LOD and the batch lists are the same
+        // for both passes of a frame (huffman_hqs/depth.cu:197-227 == render.cu:362-392), only the LDS pixel size differs
+        if (MODE == MODE_HQS_DEPTH) a.win_hqs = plan_slot[1];
+        slots = MODE == MODE_HQS_DEPTH ? 3u : my_slot;
         c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
         hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
+        a.win_hqs = nullptr;
+    }
+    if (MODE == MODE_HQS_DEPTH && (slots & 2u)) {
+        // what the colour pass of this frame needs is in place: it runs no prepass of its own if it is given the same parameters
+        c->prepass_ready = true; c->prepass_slots = 2u;
+        c->prepass_params = *p; c->prepass_variant_hqs = variant_hqs; c->prepass_dyn_lds = dyn_lds; c->prepass_batches = nB;
     }
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
@@ -500,7 +520,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096, acc)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32, acc)) ||
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) || (rc = dalloc_zero(c, c->d_colors_t, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) ||
         (rc = dalloc_zero(c, c->d_lod, nB, acc)) ||
-        (rc = dalloc_zero(c, c->d_win, nB, acc)) ||
+        (rc = dalloc_zero(c, c->d_win, 2 * nB, acc)) ||
         (rc = dalloc_zero(c, c->d_lane_words, lw_batches * LW_ROWS * PCR_WORKGROUP_SIZE, acc)) || (rc = dalloc_zero(c, c->d_batch_flags, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
         (rc = dalloc_zero(c, c->d_batch_runs, nB * RUN_WORDS, acc)) ||
@@ -600,6 +620,9 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
             int rc = dalloc_zero(c, c->d_colors, nB * color_bytes, &c->stream_bytes);
             if (!rc) rc = dalloc_zero(c, c->d_colors_t, nB * color_bytes, &c->stream_bytes);
             if (rc) return rc;
+            // the zero fill was enqueued on the context's stream; the copies and k_transcode's colors_t writes below may run on
+            // the loader stream (pcr_set_async_upload), which nothing orders behind it: drain it first, as pcr_stream_begin does
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
         c->color_bytes = color_bytes;
     }
@@ -676,6 +699,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     // the caller's records were copied into the arena: they may be released on return; the device copies complete in
     // stream order before any later render call
     c->enc_ptr = enc_ptr; c->sep_ptr = sep_ptr;
+    for (const View &v : views) c->h_stream_words.push_back(v.ne + v.ns);
     c->batches_loaded += count; c->points_loaded += count * PCR_POINTS_PER_BATCH;   // HuffmanLasLoader.cpp:294-295
     enqueue_transcode(c, false, st);    // this context's HBM layout of the stream is part of loading it
     HIP_TRY(c, hipGetLastError());
@@ -791,6 +815,23 @@ int64_t pcr_stream_algorithmic_bytes(const pcr_ctx *c)
     return c->enc_ptr * 4 + c->sep_ptr * 4 + c->batches_loaded * per_batch;
 }
 
+int64_t pcr_last_frame_algorithmic_bytes(pcr_ctx *c)
+{
+    if (!c || !c->stream_open || c->last_frame_batches <= 0) return 0;
+    const size_t nB = (size_t)std::min<int64_t>(c->last_frame_batches, (int64_t)c->h_stream_words.size());
+    std::vector<uint32_t> lod(nB);
+    if (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync(lod.data(), c->d_lod, nB * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    const int64_t per_batch = 128 + 160 + 12288 + 4096 + 32768;
+    int64_t bytes = 0;
+    for (size_t b = 0; b < nB; ++b) {
+        const uint32_t npr = lod[b] & LOD_NPR_MASK;
+        if ((lod[b] & LOD_CULLED) || npr == 0) continue;
+        bytes += per_batch + (4 * (int64_t)c->h_stream_words[b] * (int64_t)npr) / PCR_POINTS_PER_THREAD;
+    }
+    return bytes;
+}
+
 // ---- method ------------------------------------------------------------------------------------
 int pcr_set_image_size(pcr_ctx *c, int w, int h)
 {
@@ -803,10 +844,18 @@ int pcr_set_image_size(pcr_ctx *c, int w, int h)
     if (external) return set_err(c, PCR_E_ARG, "release external buffers before resizing");
     free_frame_buffers(c);
     c->width = w; c->height = h; c->fb_elems = pcr_fb_elems(w, h);
-    HIP_TRY(c, hipMalloc((void **)&c->own_fb, c->fb_elems * 8));
-    HIP_TRY(c, hipMalloc((void **)&c->own_rg, c->fb_elems * 8));
-    HIP_TRY(c, hipMalloc((void **)&c->own_ba, c->fb_elems * 8));
-    HIP_TRY(c, hipMalloc((void **)&c->d_rgba, (size_t)w * h * 4));
+    // PCR_FRAME_PAD_ELEMS behind every buffer: a frame cut into N equal slices for the sliced multi-GPU exchange
+    // (include/pcr_dist.h) reaches up to 2 N words past fb_elems. The pads are written here once -- identity of min / sum --
+    // and by nothing else but those collectives, which leave them as they were.
+    c->fb_alloc = c->fb_elems + PCR_FRAME_PAD_ELEMS;
+    HIP_TRY(c, hipMalloc((void **)&c->own_fb, c->fb_alloc * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->own_rg, c->fb_alloc * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->own_ba, c->fb_alloc * 8));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rgba, c->fb_alloc * 4));
+    HIP_TRY(c, hipMemsetAsync(c->own_fb + c->fb_elems, 0xFF, PCR_FRAME_PAD_ELEMS * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->own_rg + c->fb_elems, 0, PCR_FRAME_PAD_ELEMS * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->own_ba + c->fb_elems, 0, PCR_FRAME_PAD_ELEMS * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_rgba, 0, c->fb_alloc * 4, c->stream));
     c->fb = c->own_fb; c->rg = c->own_rg; c->ba = c->own_ba;
     c->accum_dirty = true;
     return pcr_clear(c);
@@ -843,6 +892,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     maybe_finalize(c);
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
+    if (method == PCR_METHOD_HQS) a.win_hqs = c->d_win + c->hdr.num_batches;     // ... and the colour pass's plan with it
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
@@ -850,7 +900,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     c->prepass_ready = true;
-    c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_pixel_bytes = a.win_pixel_bytes;
+    c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_slots = a.win_hqs ? 3u : 1u;
     c->prepass_dyn_lds = a.dyn_lds_bytes;
     c->prepass_batches = nB;
     return PCR_OK;
@@ -885,6 +935,7 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
     maybe_finalize(c);
     RenderArgs a = make_args(c, p_next, hqs);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;
+    if (hqs) a.win_hqs = c->d_win + c->hdr.num_batches;
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     const unsigned grid = (unsigned)c->stats_partials + 2048u;
@@ -896,7 +947,7 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     c->prepass_ready = true;
-    c->prepass_params = *p_next; c->prepass_variant_hqs = a.variant_hqs; c->prepass_win_pixel_bytes = a.win_pixel_bytes;
+    c->prepass_params = *p_next; c->prepass_variant_hqs = a.variant_hqs; c->prepass_slots = a.win_hqs ? 3u : 1u;
     c->prepass_dyn_lds = a.dyn_lds_bytes;
     c->prepass_batches = nB;
     return PCR_OK;
@@ -923,7 +974,7 @@ int pcr_render_hqs_color(pcr_ctx *c, const pcr_render_params *p)
 {
     if (c && (!c->rg || !c->ba)) return set_err(c, PCR_E_ARG, "no RG/BA accumulation buffers");
     if (c) c->accum_dirty = true;
-    if (c->stream_open && c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7) return launch_render<MODE_HQS_COLOR_BC7>(c, p);
+    if (c && c->stream_open && c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7) return launch_render<MODE_HQS_COLOR_BC7>(c, p);
     return launch_render<MODE_HQS_COLOR>(c, p);
 }
 
@@ -1113,6 +1164,12 @@ int pcr_read_rgba(pcr_ctx *c, uint32_t *host, size_t n)
 void *pcr_get_stream(pcr_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int pcr_get_device(const pcr_ctx *c) { return c ? c->device : -1; }
 size_t pcr_framebuffer_elems(const pcr_ctx *c) { return c ? c->fb_elems : 0; }
+size_t pcr_framebuffer_capacity(const pcr_ctx *c)
+{
+    if (!c || !c->fb) return 0;
+    return (c->fb == c->own_fb && c->rg == c->own_rg && c->ba == c->own_ba) ? c->fb_alloc : c->fb_elems;
+}
+void *pcr_device_rgba(pcr_ctx *c) { return c ? c->d_rgba : nullptr; }
 void *pcr_device_framebuffer(pcr_ctx *c) { return c ? c->fb : nullptr; }
 void *pcr_device_rg(pcr_ctx *c) { return c ? c->rg : nullptr; }
 void *pcr_device_ba(pcr_ctx *c) { return c ? c->ba : nullptr; }
@@ -1150,6 +1207,17 @@ int pcr_resolve_basic_range(pcr_ctx *c, const pcr_render_params *p, const void *
     if (count == 0) return PCR_OK;
     hipLaunchKernelGGL(k_resolve_range, dim3(128), dim3(256), 0, c->stream, p->show_num_points, p->colorize_chunks,
                        (const uint64_t *)fb, count, (uint32_t *)rgba);
+    HIP_TRY(c, hipGetLastError());
+    return PCR_OK;
+}
+
+int pcr_resolve_hqs_range(pcr_ctx *c, const pcr_render_params *p, const void *fb, const void *rg, const void *ba, size_t count, void *rgba)
+{
+    if (!c || !p || !fb || !rg || !ba || !rgba) return PCR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (count == 0) return PCR_OK;
+    hipLaunchKernelGGL(k_resolve_range_hqs, dim3(128), dim3(256), 0, c->stream, p->show_num_points, p->colorize_chunks,
+                       (const uint64_t *)fb, (const uint64_t *)rg, (const uint64_t *)ba, count, (uint32_t *)rgba);
     HIP_TRY(c, hipGetLastError());
     return PCR_OK;
 }

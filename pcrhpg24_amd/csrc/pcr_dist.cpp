@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,12 @@ struct pcr_dist {
     pcr_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    int exchange = PCR_DIST_EXCHANGE_AUTO;
+    // PCR_DIST_EXCHANGE_SLICED_P2P: everyone's copy of the slice this rank owns, back to back (world x slice words)
+    uint64_t *scratch = nullptr;
+    size_t scratch_elems = 0;
+    const void *merged_slice = nullptr;          // where the last pcr_dist_merge_min_sliced left this rank's merged slice
+    size_t pending_min_slices = 0;               // P2P: words per slice of an all-to-all whose local min has not been enqueued yet
 };
 
 namespace {
@@ -38,6 +45,35 @@ int fail(int code, const char *fmt, ...)
         int r_ = (call);                                                                                   \
         if (r_ != PCR_OK) return fail(r_, "rank %d: %s: %s", (d)->rank, #call, pcr_last_error((d)->ctx));  \
     } while (0)
+
+struct Slice { size_t first, count; };
+Slice slice_of(size_t elems, int world, int rank)
+{
+    const size_t S = ((elems + (size_t)world - 1) / (size_t)world + 1) & ~(size_t)1;
+    return { (size_t)rank * S, S };
+}
+
+// the frame cut into d->world slices has to fit the context's buffers (own buffers carry PCR_FRAME_PAD_ELEMS of slack)
+int check_sliced(pcr_dist *d, Slice *mine)
+{
+    const size_t n = pcr_framebuffer_elems(d->ctx), cap = pcr_framebuffer_capacity(d->ctx);
+    if (!n) return fail(PCR_E_ARG, "rank %d has no framebuffer", d->rank);
+    const Slice s = slice_of(n, d->world, d->rank);
+    if ((size_t)d->world * s.count > cap)
+        return fail(PCR_E_ARG, "rank %d: %d slices of %zu words need %zu words, the framebuffers hold %zu (external buffers carry no pad)",
+                    d->rank, d->world, s.count, (size_t)d->world * s.count, cap);
+    *mine = s;
+    return PCR_OK;
+}
+
+int reduce_scatter_u64(pcr_dist *d, void *buf, Slice s, ncclRedOp_t op)
+{
+    hipStream_t st = (hipStream_t)pcr_get_stream(d->ctx);
+    if (hipSetDevice(pcr_get_device(d->ctx)) != hipSuccess) return fail(PCR_E_HIP, "hipSetDevice failed");
+    // in place: recvbuff == sendbuff + rank * recvcount
+    NCCL_TRY(ncclReduceScatter(buf, (uint64_t *)buf + s.first, s.count, ncclUint64, op, d->comm, st));
+    return PCR_OK;
+}
 
 int reduce_u64(pcr_dist *d, void *buf, size_t count, ncclRedOp_t op, int root)
 {
@@ -94,11 +130,20 @@ int pcr_dist_create_local(pcr_ctx *const *ctxs, int n, pcr_dist **out)
         for (int j = 0; j < i; ++j)
             if (devs[(size_t)j] == devs[(size_t)i]) return fail(PCR_E_ARG, "contexts %d and %d share device %d: one rank per GPU", j, i, devs[(size_t)i]);
     }
-    std::vector<ncclComm_t> comms((size_t)n);
-    NCCL_TRY(ncclCommInitAll(comms.data(), n, devs.data()));
-    for (int i = 0; i < n; ++i) {
-        out[i] = new pcr_dist();
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    ncclResult_t r = ncclCommInitAll(comms.data(), n, devs.data());
+    bool ok = r == ncclSuccess;
+    for (int i = 0; ok && i < n; ++i) {
+        out[i] = new (std::nothrow) pcr_dist();
+        if (!out[i]) { ok = false; break; }
         out[i]->ctx = ctxs[i]; out[i]->comm = comms[(size_t)i]; out[i]->rank = i; out[i]->world = n;
+        comms[(size_t)i] = nullptr;             // owned by out[i] from here on
+    }
+    if (!ok) {                                  // nothing half-made is handed back
+        for (int i = 0; i < n; ++i) { pcr_dist_destroy(out[i]); out[i] = nullptr; }
+        for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+        return r != ncclSuccess ? fail(PCR_E_HIP, "ncclCommInitAll failed: %s", ncclGetErrorString(r)) : fail(PCR_E_NOMEM, "out of host memory");
     }
     return PCR_OK;
 }
@@ -106,8 +151,128 @@ int pcr_dist_create_local(pcr_ctx *const *ctxs, int n, pcr_dist **out)
 void pcr_dist_destroy(pcr_dist *d)
 {
     if (!d) return;
+    if (d->scratch) {
+        (void)hipSetDevice(pcr_get_device(d->ctx));
+        (void)hipStreamSynchronize((hipStream_t)pcr_get_stream(d->ctx));
+        (void)hipFree(d->scratch);
+    }
     if (d->comm) (void)ncclCommDestroy(d->comm);
     delete d;
+}
+
+int pcr_dist_set_exchange(pcr_dist *d, int mode)
+{
+    if (!d) return fail(PCR_E_ARG, "dist is NULL");
+    if (mode < PCR_DIST_EXCHANGE_AUTO || mode > PCR_DIST_EXCHANGE_SLICED_P2P) return fail(PCR_E_ARG, "unknown exchange %d", mode);
+    d->exchange = mode;
+    return PCR_OK;
+}
+
+int pcr_dist_exchange(const pcr_dist *d)
+{
+    if (!d) return PCR_DIST_EXCHANGE_REDUCE;
+    if (d->exchange != PCR_DIST_EXCHANGE_AUTO) return d->exchange;
+    return d->world > 1 && pcr_framebuffer_elems(d->ctx) * 8 >= (size_t)PCR_DIST_SLICED_MIN_BYTES ? PCR_DIST_EXCHANGE_SLICED
+                                                                                                  : PCR_DIST_EXCHANGE_REDUCE;
+}
+
+void pcr_dist_slice_range(size_t elems, int world, int rank, size_t *first, size_t *count)
+{
+    const Slice s = slice_of(elems, world < 1 ? 1 : world, rank);
+    if (first) *first = s.first;
+    if (count) *count = s.count;
+}
+
+const void *pcr_dist_merged_slice(pcr_dist *d)
+{
+    if (!d) return nullptr;
+    if (d->pending_min_slices) {
+        // behind the all-to-all in stream order (which, inside a group, is only enqueued by pcr_dist_group_end: hence here)
+        const size_t S = d->pending_min_slices;
+        d->pending_min_slices = 0;
+        if (pcr_merge_min_slices(d->ctx, d->scratch, d->world, S) != PCR_OK) { fail(PCR_E_HIP, "rank %d: pcr_merge_min_slices: %s", d->rank, pcr_last_error(d->ctx)); return nullptr; }
+    }
+    return d->merged_slice;
+}
+
+int pcr_dist_merge_min_sliced(pcr_dist *d)
+{
+    if (!d) return fail(PCR_E_ARG, "dist is NULL");
+    Slice s;
+    int rc = check_sliced(d, &s);
+    if (rc) return rc;
+    uint64_t *fb = (uint64_t *)pcr_device_framebuffer(d->ctx);
+    d->pending_min_slices = 0;
+    if (d->exchange != PCR_DIST_EXCHANGE_SLICED_P2P) {
+        d->merged_slice = fb + s.first;
+        return reduce_scatter_u64(d, fb, s, ncclMin);
+    }
+    // point to point: slice j of my frame goes to rank j over the link between us, everyone's copy of my slice comes back;
+    // the min over the copies is a local kernel (pcr_merge_min_slices)
+    hipStream_t st = (hipStream_t)pcr_get_stream(d->ctx);
+    if (hipSetDevice(pcr_get_device(d->ctx)) != hipSuccess) return fail(PCR_E_HIP, "hipSetDevice failed");
+    const size_t need = (size_t)d->world * s.count;
+    if (d->scratch_elems < need) {
+        if (d->scratch) { (void)hipStreamSynchronize(st); (void)hipFree(d->scratch); d->scratch = nullptr; d->scratch_elems = 0; }
+        if (hipMalloc((void **)&d->scratch, need * 8) != hipSuccess) return fail(PCR_E_NOMEM, "rank %d: no memory for %zu scratch words", d->rank, need);
+        d->scratch_elems = need;
+    }
+    NCCL_TRY(ncclAllToAll(fb, d->scratch, s.count, ncclUint64, d->comm, st));
+    d->merged_slice = d->scratch;
+    d->pending_min_slices = s.count;             // the local min is enqueued by pcr_dist_merged_slice
+    return PCR_OK;
+}
+
+int pcr_dist_merge_sum_sliced(pcr_dist *d)
+{
+    if (!d) return fail(PCR_E_ARG, "dist is NULL");
+    Slice s;
+    int rc = check_sliced(d, &s);
+    if (rc) return rc;
+    void *rg = pcr_device_rg(d->ctx), *ba = pcr_device_ba(d->ctx);
+    if (!rg || !ba) return fail(PCR_E_ARG, "rank %d has no accumulation buffers", d->rank);
+    NCCL_TRY(ncclGroupStart());
+    rc = reduce_scatter_u64(d, rg, s, ncclSum);
+    if (rc == PCR_OK) rc = reduce_scatter_u64(d, ba, s, ncclSum);
+    NCCL_TRY(ncclGroupEnd());
+    return rc;
+}
+
+int pcr_dist_gather_image(pcr_dist *d, int root)
+{
+    if (!d) return fail(PCR_E_ARG, "dist is NULL");
+    if (root != PCR_DIST_ALL && (root < 0 || root >= d->world)) return fail(PCR_E_ARG, "root %d out of range", root);
+    Slice s;
+    int rc = check_sliced(d, &s);
+    if (rc) return rc;
+    uint32_t *rgba = (uint32_t *)pcr_device_rgba(d->ctx);
+    if (!rgba) return fail(PCR_E_ARG, "rank %d has no image buffer", d->rank);
+    hipStream_t st = (hipStream_t)pcr_get_stream(d->ctx);
+    if (hipSetDevice(pcr_get_device(d->ctx)) != hipSuccess) return fail(PCR_E_HIP, "hipSetDevice failed");
+    // in place: sendbuff == recvbuff + rank * sendcount
+    if (root == PCR_DIST_ALL) NCCL_TRY(ncclAllGather(rgba + s.first, rgba, s.count, ncclUint32, d->comm, st));
+    else                      NCCL_TRY(ncclGather(rgba + s.first, rgba, s.count, ncclUint32, root, d->comm, st));
+    return PCR_OK;
+}
+
+// pixels of the image that lie in this rank's slice
+static size_t slice_pixels(const pcr_render_params *p, Slice s)
+{
+    const size_t px = (size_t)p->width * (size_t)p->height;
+    return s.first < px ? (s.count < px - s.first ? s.count : px - s.first) : 0;
+}
+
+// merge + resolve + gather of a basic frame, sliced form (everything but the render and the clear)
+static int basic_exchange_sliced(pcr_dist *d, const pcr_render_params *p, int root)
+{
+    int rc = pcr_dist_merge_min_sliced(d);
+    if (rc) return rc;
+    Slice s;
+    if ((rc = check_sliced(d, &s))) return rc;
+    const void *merged = pcr_dist_merged_slice(d);
+    if (!merged) return PCR_E_HIP;
+    PCR_TRY(d, pcr_resolve_basic_range(d->ctx, p, merged, slice_pixels(p, s), (uint32_t *)pcr_device_rgba(d->ctx) + s.first));
+    return pcr_dist_gather_image(d, root);
 }
 
 int pcr_dist_rank(const pcr_dist *d) { return d ? d->rank : -1; }
@@ -145,6 +310,7 @@ int pcr_dist_frame_basic(pcr_dist *d, const pcr_render_params *p, int root)
     if (!d || !p) return fail(PCR_E_ARG, "bad arguments");
     PCR_TRY(d, pcr_frame_begin(d->ctx, p, PCR_METHOD_BASIC));      // CLEAR + cull/LOD prepass
     PCR_TRY(d, pcr_render_basic(d->ctx, p));
+    if (pcr_dist_exchange(d) != PCR_DIST_EXCHANGE_REDUCE) return basic_exchange_sliced(d, p, root);
     int rc = pcr_dist_merge_min(d, root);
     if (rc) return rc;
     if (root == PCR_DIST_ALL || root == d->rank) PCR_TRY(d, pcr_resolve_basic(d->ctx, p));
@@ -158,6 +324,13 @@ int pcr_dist_step_basic(pcr_dist *d, const pcr_render_params *p, int root)
 {
     if (!d || !p) return fail(PCR_E_ARG, "bad arguments");
     PCR_TRY(d, pcr_render_basic(d->ctx, p));
+    if (pcr_dist_exchange(d) != PCR_DIST_EXCHANGE_REDUCE) {
+        // the image is resolved slice by slice on the ranks that own the slices; what is left of the frame's end is CLEAR + prepass
+        int rcs = basic_exchange_sliced(d, p, root);
+        if (rcs) return rcs;
+        PCR_TRY(d, pcr_frame_begin(d->ctx, p, PCR_METHOD_BASIC));
+        return PCR_OK;
+    }
     int rc = pcr_dist_merge_min(d, root);
     if (rc) return rc;
     if (root == PCR_DIST_ALL || root == d->rank) PCR_TRY(d, pcr_frame_turn(d->ctx, p, p, PCR_METHOD_BASIC));
@@ -173,6 +346,16 @@ int pcr_dist_frame_hqs(pcr_dist *d, const pcr_render_params *p, int root)
     int rc = pcr_dist_merge_min(d, PCR_DIST_ALL);                 // every rank needs the global depth for its 1 % test
     if (rc) return rc;
     PCR_TRY(d, pcr_render_hqs_color(d->ctx, p));
+    if (pcr_dist_exchange(d) != PCR_DIST_EXCHANGE_REDUCE) {
+        // sums reduce-scattered: every rank divides the pixels of its slice (it holds the global depth words already)
+        if ((rc = pcr_dist_merge_sum_sliced(d))) return rc;
+        Slice s;
+        if ((rc = check_sliced(d, &s))) return rc;
+        PCR_TRY(d, pcr_resolve_hqs_range(d->ctx, p, (const uint64_t *)pcr_device_framebuffer(d->ctx) + s.first,
+                                         (const uint64_t *)pcr_device_rg(d->ctx) + s.first, (const uint64_t *)pcr_device_ba(d->ctx) + s.first,
+                                         slice_pixels(p, s), (uint32_t *)pcr_device_rgba(d->ctx) + s.first));
+        return pcr_dist_gather_image(d, root);
+    }
     rc = pcr_dist_merge_sum(d, root);
     if (rc) return rc;
     if (root == PCR_DIST_ALL || root == d->rank) PCR_TRY(d, pcr_resolve_hqs(d->ctx, p));

@@ -156,7 +156,9 @@ struct RenderArgs {
     StreamView s;
     FrameView f;
     uint32_t *lod;            // [nB]
-    WinPlan *win;             // [nB] LDS framebuffer windows per batch
+    WinPlan *win;             // [nB] LDS framebuffer windows per batch, for pixels of win_pixel_bytes
+    WinPlan *win_hqs;         // prepass only: if not NULL, a second plan for the 20-byte pixels of the HQS colour pass is written here
+                              // (the depth pass's prepass serves the colour pass of the same frame: one prepass per frame)
     pcr_render_stats *stats;  // device: one partial record per prepass workgroup
     // Dense lists of the batches k_render has to draw (frustum-culled batches and batches whose level of detail is zero
     // points are left out), compacted by the prepass in two levels that keep the file's (Morton) order: every prepass
@@ -285,11 +287,45 @@ __device__ __forceinline__ void rect_pack(IRect r, uint32_t &xy, uint32_t &wh)
     wh = (uint32_t)(r.x1 - r.x0 + 1) | ((uint32_t)(r.y1 - r.y0 + 1) << 16);
 }
 
+// Windows for one pixel size, given the run's rectangle `mine` and the batch's own rectangle `whole` (uniform work per RUNS lanes).
+__device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect whole, const uint32_t *runs, int r, WinPlan *out)
+{
+    auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
+    auto group_max = [](int v) { v = max(v, __shfl_xor(v, 1, RUNS)); v = max(v, __shfl_xor(v, 2, RUNS)); return v; };
+    const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };
+    // The rectangle of the batch's own bounding box (GPUBatch: it holds every point, the runs' boxes leave the straddling chains
+    // out): if the LDS holds it, it is the one window of the batch and no point lands outside.
+    if (rect_area(whole) > 0 && rect_area(whole) <= cap) {
+        uint32_t xy = 0, wh = 0;
+        if (r == 0) rect_pack(whole, xy, wh);
+        out->xy[r] = xy; out->wh[r] = wh;                                           // (runs 1..3: no window of their own)
+        if (r < RUNS - 1) out->first[r] = PCR_WORKGROUP_SIZE;                       // every chain belongs to run 0
+        if (r == 0) out->reserved = 0;
+        return;
+    }
+    // one window per run; while they do not fit together, the largest gives way (a run with a jump of its own inside)
+    int sum = group_sum(rect_area(mine));
+#pragma unroll 1
+    for (int round = 0; round < 6 && sum > cap; ++round) {
+        const int area = rect_area(mine), largest = group_max(area);
+        // (ties: every holder of the largest area shrinks -- the loop ends all the same)
+        if (area == largest) {
+            const int target = max(largest - (sum - cap), largest / 4);
+            mine = target >= 1 ? rect_shrink(mine, sqrtf((float)target / (float)largest)) : none;
+        }
+        sum = group_sum(rect_area(mine));
+    }
+    if (sum > cap) mine = none;                                                     // hopeless: this run goes the global way
+    rect_pack(mine, out->xy[r], out->wh[r]);
+    if (r < RUNS - 1) out->first[r] = min(runs[r], (uint32_t)PCR_WORKGROUP_SIZE);
+    if (r == 0) out->reserved = 0;
+}
+
 __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int r)
 {
     const pcr_render_params &p = a.p;
     const float fw = (float)p.width, fh = (float)p.height;
-    const int cap = window_capacity((uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023], a.win_pixel_bytes, a.dyn_lds_bytes);
+    const uint32_t esc_total = (uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023];
     const uint32_t *runs = a.s.batch_runs + (size_t)b * RUN_WORDS;
     const float *box = reinterpret_cast<const float *>(runs + 4 + r * 6);
     const float bmin[3] = { box[0], box[1], box[2] }, bmax[3] = { box[3], box[4], box[5] };
@@ -315,11 +351,6 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
         }
     }
     auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
-    auto group_max = [](int v) { v = max(v, __shfl_xor(v, 1, RUNS)); v = max(v, __shfl_xor(v, 2, RUNS)); return v; };
-    int sum = group_sum(rect_area(mine));
-    WinPlan *out = a.win + b;
-    // The rectangle of the batch's own bounding box (GPUBatch: it holds every point, the runs' boxes leave the straddling chains
-    // out): if the LDS holds it, it is the one window of the batch and no point lands outside.
     IRect whole = none;
     {
         const pcr_gpu_batch *g = a.s.batches + b;
@@ -349,29 +380,9 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
             whole.y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1); whole.y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
         }
     }
-    if (rect_area(whole) > 0 && rect_area(whole) <= cap) {
-        uint32_t xy = 0, wh = 0;
-        if (r == 0) rect_pack(whole, xy, wh);
-        out->xy[r] = xy; out->wh[r] = wh;                                           // (runs 1..3: no window of their own)
-        if (r < RUNS - 1) out->first[r] = PCR_WORKGROUP_SIZE;                       // every chain belongs to run 0
-        if (r == 0) out->reserved = 0;
-        return;
-    }
-    // one window per run; while they do not fit together, the largest gives way (a run with a jump of its own inside)
-#pragma unroll 1
-    for (int round = 0; round < 6 && sum > cap; ++round) {
-        const int area = rect_area(mine), largest = group_max(area);
-        // (ties: every holder of the largest area shrinks -- the loop ends all the same)
-        if (area == largest) {
-            const int target = max(largest - (sum - cap), largest / 4);
-            mine = target >= 1 ? rect_shrink(mine, sqrtf((float)target / (float)largest)) : none;
-        }
-        sum = group_sum(rect_area(mine));
-    }
-    if (sum > cap) mine = none;                                                     // hopeless: this run goes the global way
-    rect_pack(mine, out->xy[r], out->wh[r]);
-    if (r < RUNS - 1) out->first[r] = min(runs[r], (uint32_t)PCR_WORKGROUP_SIZE);
-    if (r == 0) out->reserved = 0;
+    assign_windows(window_capacity(esc_total, a.win_pixel_bytes, a.dyn_lds_bytes), mine, whole, runs, r, a.win + b);
+    if (a.win_hqs)                                              // (uniform) the colour pass of the same frame: 20-byte pixels
+        assign_windows(window_capacity(esc_total, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes), mine, whole, runs, r, a.win_hqs + b);
 }
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
@@ -1681,6 +1692,31 @@ __global__ void __launch_bounds__(256) k_resolve_range(int show_num_points, int 
                 color = id * 1234567u;
             } else {
                 color = id;
+            }
+        }
+        rgba[i] = color;
+    }
+}
+
+// The HQS resolve of a contiguous range of pixels (a slice of the frame a rank owns after the sums were reduce-scattered):
+// same arithmetic as k_resolve<true>, which depends on the pixel's three words only.
+__global__ void __launch_bounds__(256) k_resolve_range_hqs(int show_num_points, int colorize_chunks, const uint64_t *fb,
+                                                           const uint64_t *rg, const uint64_t *ba, size_t count, uint32_t *rgba)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t id = (uint32_t)fb[i];
+        uint32_t color = PCR_BACKGROUND_COLOR;
+        if (id < 0xFFFFFFFFu) {
+            if (show_num_points) {
+                const uint32_t shade = (uint32_t)(((double)(float)(int)id / 512.0) * 255.0);
+                color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+            } else if (colorize_chunks) {
+                color = id * 1234567u;
+            } else {
+                const uint64_t vrg = rg[i], vba = ba[i];
+                const uint32_t cnt = (uint32_t)vba;
+                if (cnt == 0) color = 0;
+                else color = (((uint32_t)(vba >> 32) / cnt) << 16) | (((uint32_t)vrg / cnt) << 8) | ((uint32_t)(vrg >> 32) / cnt);
             }
         }
         rgba[i] = color;

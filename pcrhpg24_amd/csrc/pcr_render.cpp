@@ -94,18 +94,18 @@ int main(int argc, char **argv)
         pcr_render_stats st;
         renderer.check(pcr_get_stats(renderer.ctx, &st), "pcr_get_stats");
         if (!dump_fb.empty()) std::ofstream(dump_fb, std::ios::binary).write((const char *)fb.data(), (std::streamsize)(fb.size() * 8));
+        std::vector<uint32_t> rgba((size_t)w * h);
+        renderer.check(pcr_read_rgba(renderer.ctx, rgba.data(), rgba.size()), "pcr_read_rgba");
         if (!dump_rgba.empty()) {
-            std::vector<uint32_t> rgba((size_t)w * h);
-            renderer.check(pcr_read_rgba(renderer.ctx, rgba.data(), rgba.size()), "pcr_read_rgba");
             std::ofstream o(dump_rgba, std::ios::binary);
             o << "P6\n" << w << " " << h << "\n255\n";
             for (int y = h - 1; y >= 0; --y)          // GL convention: row 0 is the bottom
                 for (int x = 0; x < w; ++x) { uint32_t c = rgba[(size_t)y * w + x]; char px[3] = {(char)(c & 255), (char)((c >> 8) & 255), (char)((c >> 16) & 255)}; o.write(px, 3); }
         }
         std::printf("{\"method\": \"%s\", \"batches\": %lld, \"frames_to_load\": %d, \"last_frame_ms\": %.3f, \"points_iterated\": %lld, "
-                    "\"batches_culled\": %lld, \"covered_pixels\": %zu, \"fb_fnv1a\": \"%016llx\"}\n",
+                    "\"batches_culled\": %lld, \"covered_pixels\": %zu, \"fb_fnv1a\": \"%016llx\", \"rgba_fnv1a\": \"%016llx\"}\n",
                     selected->name.c_str(), (long long)(las_huffman ? las_huffman->numBatches : las_compute->numBatchesLoaded), n, ms, (long long)st.points_iterated,
-                    (long long)st.batches_culled, covered, (unsigned long long)fnv1a(fb.data(), fb.size() * 8));
+                    (long long)st.batches_culled, covered, (unsigned long long)fnv1a(fb.data(), fb.size() * 8), (unsigned long long)fnv1a(rgba.data(), rgba.size() * 4));
         Runtime::resource->unload(&renderer);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "pcr_render: %s\n", e.what());

@@ -5,8 +5,12 @@
 //
 //   pcr_render_dist <file.huffman> --ranks N [--method huffman_mem_iter_cuda|huffman_hqs] [--size WxH]
 //                   [--camera yaw pitch radius tx ty tz] [--lod 0.1] [--cull 0|1] [--frames K] [--allreduce]
-// Prints one JSON line: ranks, batches per rank, ms per frame, FNV-1a of rank 0's merged u64 framebuffer -- the same hash
-// pcr_render prints for the same file and camera on one GPU (min and + are associative: the merge is bit-exact).
+//                   [--merge auto|reduce|sliced|sliced_p2p]
+// --merge sliced: the frame is cut into N slices, reduce-scattered (sliced_p2p: all-to-all + local min), every rank resolves
+// the slice it owns and the RGBA8 image is gathered on rank 0 (--allreduce: on every rank); auto = sliced from 64 MB frames on.
+// Prints one JSON line: ranks, batches per rank, ms per frame, FNV-1a of rank 0's image (rgba_fnv1a) and -- for the
+// whole-frame merges, after which rank 0 holds it -- of the merged u64 framebuffer (fb_fnv1a): the hashes pcr_render prints
+// for the same file and camera on one GPU (min and + are associative: the merge is bit-exact).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +36,9 @@ struct File {                                       // HuffmanLasData::loadHeade
     int64_t num_batches = 0;
     std::vector<int64_t> offset;                    // record offsets, num_batches + 1
     static constexpr size_t FIXED = PCR_BATCH_FIXED_HEADER;
-    void stream_lengths(int64_t b, int32_t *ne, int32_t *ns) const
+    // the part of a record in front of its two streams: header + start values + escape prefix + tables + cluster prefix
+    static constexpr size_t SIDE = PCR_BATCH_FIXED_HEADER + 4 * (3072 + 1024 + 4096 + 4096 + 32);
+    void stream_lengths(int64_t b, int32_t *ne, int32_t *ns) const       // (read_file checked that the record holds its side data)
     {
         const uint8_t *r = bytes.data() + offset[(size_t)b] + FIXED;
         std::memcpy(ns, r + 4 * 3072 + 4 * 1023, 4);
@@ -60,8 +66,16 @@ static File read_file(const std::string &path)
     for (int64_t b = 0; b < f.num_batches; ++b) {
         int64_t sz;
         std::memcpy(&sz, f.bytes.data() + 40 + 8 * b, 8);
-        if (sz < (int64_t)File::FIXED || off + sz > n) throw std::runtime_error("batch record " + std::to_string(b) + " exceeds the file");
+        // a record holds at least its side data and one colour array; its two stream lengths (read from inside it) have to
+        // add up to its size -- checked here, before anything indexes into a record (the library validates the same again)
+        if (sz < (int64_t)(File::SIDE + PCR_COLOR_BYTES_PER_BATCH) || off + sz > n)
+            throw std::runtime_error("batch record " + std::to_string(b) + " is too short or exceeds the file");
         f.offset[(size_t)b] = off;
+        int32_t ne, ns;
+        f.stream_lengths(b, &ne, &ns);
+        const int64_t streams = (int64_t)File::SIDE + 4 * ((int64_t)ne + (int64_t)ns);
+        if (ne < 0 || ns < 0 || (sz != streams + PCR_COLOR_BYTES_PER_BATCH && sz != streams + PCR_COLOR_BYTES_PER_BATCH_BC7))
+            throw std::runtime_error("batch record " + std::to_string(b) + ": size " + std::to_string(sz) + " does not match its stream lengths");
         off += sz;
     }
     f.offset[(size_t)f.num_batches] = off;
@@ -77,6 +91,7 @@ int main(int argc, char **argv)
     std::string path = argv[1], method = "huffman_mem_iter_cuda";
     int w = 1920, h = 1080, frames = 20, ranks = 1, cull = 1;
     bool allreduce = false;
+    std::string merge = "auto";
     double lod = 0.1, cam[6] = {-0.15, -0.57, 3166.32, 2239.05, 1713.63, -202.02};
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
@@ -89,11 +104,15 @@ int main(int argc, char **argv)
         else if (a == "--cull") { need(1); cull = std::atoi(argv[++i]); }
         else if (a == "--frames") { need(1); frames = std::atoi(argv[++i]); }
         else if (a == "--allreduce") { allreduce = true; }
+        else if (a == "--merge") { need(1); merge = argv[++i]; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     const bool hqs = method == "huffman_hqs";
     if (!hqs && method != "huffman_mem_iter_cuda" && method != "huffman_cuda") { std::fprintf(stderr, "no method named %s\n", method.c_str()); return 2; }
     if (ranks < 1) return 2;
+    const int exchange_arg = merge == "auto" ? PCR_DIST_EXCHANGE_AUTO : merge == "reduce" ? PCR_DIST_EXCHANGE_REDUCE :
+                             merge == "sliced" ? PCR_DIST_EXCHANGE_SLICED : merge == "sliced_p2p" ? PCR_DIST_EXCHANGE_SLICED_P2P : -1;
+    if (exchange_arg < 0) { std::fprintf(stderr, "--merge auto|reduce|sliced|sliced_p2p\n"); return 2; }
     std::vector<pcr_ctx *> ctx((size_t)ranks, nullptr);
     std::vector<pcr_dist *> dist((size_t)ranks, nullptr);
     int status = 0;
@@ -143,14 +162,54 @@ int main(int argc, char **argv)
             DCHECK(pcr_dist_create_local(ctx.data(), ranks, dist.data()));
         }
         const int root = allreduce ? PCR_DIST_ALL : 0;
+        for (int r = 0; r < ranks; ++r) DCHECK(pcr_dist_set_exchange(dist[(size_t)r], exchange_arg));
+        const int exchange = pcr_dist_exchange(dist[0]);
+        const bool sliced = exchange != PCR_DIST_EXCHANGE_REDUCE;
+        const size_t pixels = (size_t)w * h;
+        // the image assembled from the slices the ranks resolved (sliced exchange): one group of gathers
+        auto gather = [&]() {
+            DCHECK(pcr_dist_group_begin());
+            for (int r = 0; r < ranks; ++r) DCHECK(pcr_dist_gather_image(dist[(size_t)r], root));
+            DCHECK(pcr_dist_group_end());
+        };
+        auto my_slice = [&](int r, size_t *first, size_t *px) {
+            size_t cnt;
+            pcr_dist_slice_range(pcr_framebuffer_elems(ctx[(size_t)r]), ranks, r, first, &cnt);
+            *px = *first < pixels ? std::min(cnt, pixels - *first) : 0;
+        };
         auto frame = [&]() {
             // one thread drives every rank: kernels are asynchronous, the collectives of the N ranks go into one group
             if (!hqs) {
                 for (int r = 0; r < ranks; ++r) { CHECK(ctx[(size_t)r], pcr_frame_begin(ctx[(size_t)r], &p, PCR_METHOD_BASIC)); CHECK(ctx[(size_t)r], pcr_render_basic(ctx[(size_t)r], &p)); }
                 DCHECK(pcr_dist_group_begin());
-                for (int r = 0; r < ranks; ++r) DCHECK(pcr_dist_merge_min(dist[(size_t)r], root));
+                for (int r = 0; r < ranks; ++r) DCHECK(sliced ? pcr_dist_merge_min_sliced(dist[(size_t)r]) : pcr_dist_merge_min(dist[(size_t)r], root));
                 DCHECK(pcr_dist_group_end());
+                if (sliced) {
+                    for (int r = 0; r < ranks; ++r) {
+                        size_t first, px; my_slice(r, &first, &px);
+                        const void *merged = pcr_dist_merged_slice(dist[(size_t)r]);
+                        if (!merged) throw std::runtime_error(std::string("pcr_dist_merged_slice: ") + pcr_dist_last_error());
+                        CHECK(ctx[(size_t)r], pcr_resolve_basic_range(ctx[(size_t)r], &p, merged, px, (uint32_t *)pcr_device_rgba(ctx[(size_t)r]) + first));
+                    }
+                    gather();
+                } else
                 for (int r = 0; r < ranks; ++r) if (allreduce || r == 0) CHECK(ctx[(size_t)r], pcr_resolve_basic(ctx[(size_t)r], &p));
+            } else if (sliced) {
+                for (int r = 0; r < ranks; ++r) { CHECK(ctx[(size_t)r], pcr_frame_begin(ctx[(size_t)r], &p, PCR_METHOD_HQS)); CHECK(ctx[(size_t)r], pcr_render_hqs_depth(ctx[(size_t)r], &p)); }
+                DCHECK(pcr_dist_group_begin());
+                for (int r = 0; r < ranks; ++r) DCHECK(pcr_dist_merge_min(dist[(size_t)r], PCR_DIST_ALL));
+                DCHECK(pcr_dist_group_end());
+                for (int r = 0; r < ranks; ++r) CHECK(ctx[(size_t)r], pcr_render_hqs_color(ctx[(size_t)r], &p));
+                DCHECK(pcr_dist_group_begin());
+                for (int r = 0; r < ranks; ++r) DCHECK(pcr_dist_merge_sum_sliced(dist[(size_t)r]));
+                DCHECK(pcr_dist_group_end());
+                for (int r = 0; r < ranks; ++r) {
+                    size_t first, px; my_slice(r, &first, &px);
+                    pcr_ctx *c = ctx[(size_t)r];
+                    CHECK(c, pcr_resolve_hqs_range(c, &p, (const uint64_t *)pcr_device_framebuffer(c) + first, (const uint64_t *)pcr_device_rg(c) + first,
+                                                   (const uint64_t *)pcr_device_ba(c) + first, px, (uint32_t *)pcr_device_rgba(c) + first));
+                }
+                gather();
             } else {
                 for (int r = 0; r < ranks; ++r) { CHECK(ctx[(size_t)r], pcr_frame_begin(ctx[(size_t)r], &p, PCR_METHOD_HQS)); CHECK(ctx[(size_t)r], pcr_render_hqs_depth(ctx[(size_t)r], &p)); }
                 DCHECK(pcr_dist_group_begin());
@@ -170,15 +229,25 @@ int main(int argc, char **argv)
         sync_all();
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(1, frames);
         std::vector<uint64_t> fb((size_t)w * h);
+        std::vector<uint32_t> rgba((size_t)w * h);
         CHECK(ctx[0], pcr_read_framebuffer(ctx[0], fb.data(), fb.size()));
+        CHECK(ctx[0], pcr_read_rgba(ctx[0], rgba.data(), rgba.size()));
         size_t covered = 0;
-        for (uint64_t v : fb) covered += v != ~0ull;
+        // (after a sliced exchange rank 0 holds only its slice of the merged u64 frame: covered pixels are counted in the image,
+        // a pixel no point reached is the background colour there: resolve.cu:166)
+        if (sliced && !hqs) for (uint32_t v : rgba) covered += v != PCR_BACKGROUND_COLOR;
+        else for (uint64_t v : fb) covered += v != ~0ull;
         int64_t points = 0;
         for (int r = 0; r < ranks; ++r) { pcr_render_stats st; CHECK(ctx[(size_t)r], pcr_get_stats(ctx[(size_t)r], &st)); points += st.points_iterated; }
+        const char *merge_name = exchange == PCR_DIST_EXCHANGE_SLICED ? (allreduce ? "reduce-scatter + all-gather of the image" : "reduce-scatter + gather of the image")
+                               : exchange == PCR_DIST_EXCHANGE_SLICED_P2P ? (allreduce ? "all-to-all + local min + all-gather of the image" : "all-to-all + local min + gather of the image")
+                               : allreduce ? "allreduce" : "reduce to rank 0";
         std::printf("{\"method\": \"%s\", \"ranks\": %d, \"batches\": %lld, \"batches_rank0\": %lld, \"merge\": \"%s\", \"ms_per_frame\": %.4f, "
-                    "\"points_iterated\": %lld, \"covered_pixels\": %zu, \"fb_fnv1a\": \"%016llx\"}\n",
-                    method.c_str(), ranks, (long long)f.num_batches, (long long)count[0], allreduce ? "allreduce" : "reduce to rank 0", ms,
-                    (long long)points, covered, (unsigned long long)fnv1a(fb.data(), fb.size() * 8));
+                    "\"points_iterated\": %lld, \"covered_pixels\": %zu, \"fb_fnv1a\": ",
+                    method.c_str(), ranks, (long long)f.num_batches, (long long)count[0], merge_name, ms, (long long)points, covered);
+        if (sliced) std::printf("null");
+        else std::printf("\"%016llx\"", (unsigned long long)fnv1a(fb.data(), fb.size() * 8));
+        std::printf(", \"rgba_fnv1a\": \"%016llx\"}\n", (unsigned long long)fnv1a(rgba.data(), rgba.size() * 4));
     } catch (const std::exception &e) {
         std::fprintf(stderr, "pcr_render_dist: %s\n", e.what());
         status = 1;

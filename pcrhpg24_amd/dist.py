@@ -7,7 +7,10 @@ the packed 64-bit words, which makes the merged result bit-identical to a single
     HQS   :  depth pass  -> all-reduce MIN (every rank then tests against the GLOBAL depth)
              colour pass -> reduce SUM of RG|BA (one buffer) to the display rank -> resolve there
 A reduce moves half the bytes of an all-reduce over the point-to-point xGMI links; `merge="allreduce"` keeps the
-finished frame on every rank instead.
+finished frame on every rank instead; `merge="sliced"` cuts the frame into N slices (all-to-all, local min, resolve of the
+own slice, all-gather of the image): 1/N of the frame per link. The C++ layer (include/pcr_dist.h, NativeDist below) has the
+same three forms on RCCL's own unsigned 64-bit min; this module is the torch.distributed transport of the tests and of
+bench.py's default at N > 1, and the gloo-runnable statement of the exchange arithmetic (tests/test_dist_cpu.py).
 
 torch.distributed is the transport (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests). It exposes signed int64 only. On the GPU path the framebuffer is made int64-mergeable instead of being
@@ -164,7 +167,7 @@ def a2a_merge(fb, recv, rgba_slice, rgba, world_size: int, min_slices, resolve_r
 
 
 class SlicedFrame:
-    """A frame for merge="a2a": torch-owned like DeviceFrame, padded to world_size equal slices, plus the receive buffer
+    """A frame for merge="sliced": torch-owned like DeviceFrame, padded to world_size equal slices, plus the receive buffer
     and the image tensors of a2a_merge."""
 
     def __init__(self, ctx, width: int, height: int, device, world_size: int):
@@ -221,7 +224,7 @@ def render_basic_sharded(ctx, frame, params, world_size: int, group=None, merge:
     ctx.render_basic(params)
     final = True
     if frame is not None:
-        if merge == "a2a":
+        if merge == "sliced":
             frame.merge_and_resolve(params, group)
             return
         if merge == "reduce":
@@ -240,91 +243,12 @@ def render_hqs_sharded(ctx, frame: Optional[DeviceFrame], params, world_size: in
     ctx.render_hqs_color(params)
     final = True
     if frame is not None:
-        if merge in ("reduce", "a2a"):      # the all-to-all form exists for the basic method only
+        if merge in ("reduce", "sliced"):      # the all-to-all form exists for the basic method only
             final = frame.reduce_sum(0, group)
         else:
             frame.allreduce_sum(group)
     if final:
         ctx.resolve_hqs(params)
-
-
-class PipelinedBasicRenderer:
-    """Basic method over shards with the exchange step overlapped: the RCCL min reduce (or all-reduce) of frame k runs on a
-    communication stream while frame k+1 is decoded and rasterized into the other of two framebuffers on the compute
-    stream; frame k is resolved on the compute stream right behind the render of frame k+1. Results are the same as
-    the one-stream form, one frame later.
-
-    Only the collective overlaps the render. Small kernels of our own next to a render do not pay: a resolve launched
-    on the communication stream takes the wave slots a finished 1024-thread workgroup frees, the next render workgroup
-    cannot start on that CU until it is done, and both kernels run slower (measured on one rank: resolve 55 us instead
-    of 7, render +7 %, step 0.380 ms instead of 0.335)."""
-
-    def __init__(self, ctx, width: int, height: int, device, group=None, merge: str = "reduce"):
-        import torch
-        import torch.distributed as dist
-        self.ctx, self.device, self.group, self.merge = ctx, device, group, merge
-        if merge == "a2a":
-            world = dist.get_world_size(group)
-            self.frames = [SlicedFrame(ctx, width, height, device, world), SlicedFrame(ctx, width, height, device, world)]
-        else:
-            self.frames = [DeviceFrame(ctx, width, height, device, accum=False), DeviceFrame(ctx, width, height, device, accum=False)]
-        self.compute = torch.cuda.Stream(device)
-        self.comm = torch.cuda.Stream(device, priority=-1)   # the collective should not queue behind a frame's 1526 workgroups
-        # stream-to-stream ordering goes through the context's device-scope fences (slots 0,1: frame i rendered; 2,3: frame
-        # i merged): a default event releases to system scope, i.e. writes the L2 with the framebuffer in it back
-        # does this rank hold (and resolve) whole merged frames? (a2a: every rank resolves its slice on the merge side)
-        self.final = merge == "allreduce" or (merge == "reduce" and dist.get_rank(group) == 0)
-        self.params = [None, None]
-        self.unresolved = [False, False]
-        self.k = 0
-
-    def _resolve(self, j: int):
-        """Frame j: wait for its merge, resolve it on the compute stream (ranks that hold the merged frame)."""
-        if not self.unresolved[j]:
-            return
-        self.unresolved[j] = False
-        if self.final:
-            self.ctx.fence_wait(2 + j, self.compute.cuda_stream)
-            self.frames[j].bind(self.compute)
-            self.ctx.resolve_basic(self.params[j])
-
-    def step(self, params):
-        import torch
-        i = self.k & 1
-        f = self.frames[i]
-        cs, ms = self.compute.cuda_stream, self.comm.cuda_stream
-        self.ctx.fence_wait(2 + i, cs)                 # this framebuffer's previous merge is done (its resolve is behind us in stream order)
-        f.bind(self.compute)
-        self.ctx.frame_begin(params)
-        self.ctx.render_basic(params)
-        self.ctx.fence_record(i, cs)
-        self.params[i] = params.copy() if hasattr(params, "copy") else params
-        self.unresolved[i] = True
-        self.ctx.fence_wait(i, ms)
-        with torch.cuda.stream(self.comm):             # RCCL orders itself against torch's current stream
-            if self.merge == "a2a":
-                f.bind(self.comm)                      # its two small kernels sit between the two collectives
-                f.merge_and_resolve(self.params[i], self.group)
-            elif self.merge == "reduce":
-                f.reduce_min(0, self.group)
-            else:
-                f.allreduce_min(self.group)
-        self.ctx.fence_record(2 + i, ms)
-        self._resolve(i ^ 1)                           # the previous frame, merged while this one was being drawn
-        self.k += 1
-
-    def last_frame(self) -> DeviceFrame:
-        return self.frames[(self.k - 1) & 1]
-
-    def finish(self):
-        if self.k:
-            self._resolve((self.k - 1) & 1)
-        self.compute.synchronize()
-        self.comm.synchronize()
-
-    def release(self):
-        self.finish()
-        self.frames[0].release()
 
 
 class NativeDist:
@@ -348,6 +272,8 @@ class NativeDist:
             getattr(lib, n).argtypes = [C.c_void_p, C.c_int]
         for n in ("pcr_dist_frame_basic", "pcr_dist_frame_hqs", "pcr_dist_step_basic"):
             getattr(lib, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.pcr_dist_set_exchange.argtypes = [C.c_void_p, C.c_int]
+        lib.pcr_dist_exchange.argtypes = [C.c_void_p]
         self.lib, self.ctx, self.rank, self.world, self._C = lib, ctx, rank, world, C
         ident = C.create_string_buffer(128)
         if rank == 0 and lib.pcr_dist_unique_id(ident) != 0:
@@ -374,6 +300,15 @@ class NativeDist:
     def step_basic(self, params, root: int = 0):
         """render + merge + (resolve, clear, next prepass in one launch); prime with ctx.frame_begin(params) once."""
         self._chk(self.lib.pcr_dist_step_basic(self.h, self._C.byref(params), root), "pcr_dist_step_basic")
+
+    EXCHANGE = {"auto": 0, "reduce": 1, "sliced": 2, "sliced_p2p": 3}
+
+    def set_exchange(self, mode: str) -> str:
+        """Which exchange the frame calls use (include/pcr_dist.h: PCR_DIST_EXCHANGE_*); returns what it resolves to for the
+        context's image size ("auto": sliced from 64 MB frames on)."""
+        self._chk(self.lib.pcr_dist_set_exchange(self.h, self.EXCHANGE[mode]), "pcr_dist_set_exchange")
+        got = self.lib.pcr_dist_exchange(self.h)
+        return {v: k for k, v in self.EXCHANGE.items()}[got]
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -313,6 +313,12 @@ class Context:
     def algorithmic_bytes(self) -> int:
         return int(self.lib.pcr_stream_algorithmic_bytes(self.h))
 
+    @property
+    def last_frame_algorithmic_bytes(self) -> int:
+        """Algorithmic bytes of the frame the last render call drew: culled batches left out, a drawn batch's words by the
+        share of its chains' points its level of detail decodes (pcr_last_frame_algorithmic_bytes; synchronises)."""
+        return int(self.lib.pcr_last_frame_algorithmic_bytes(self.h))
+
     # method side
     # -- GPU encoder (include/pcr_gpu_encode.h) ---------------------------------------------------------
     @property

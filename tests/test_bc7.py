@@ -138,3 +138,37 @@ def test_hqs_draws_a_bc7_stream_like_the_oracle(layout):
             ctx.render_basic(scenes.cameras(640, 360)["overview"])
     finally:
         r.ctx.close()
+
+
+@pytest.mark.gpu
+def test_bc7_stream_through_the_asynchronous_loader():
+    """The first records of a BC7 stream make the context re-allocate its colour arrays (they were sized for BC1); with
+    pcr_set_async_upload the copies and k_transcode run on the loader stream, so the zero fill of the new arrays has to be
+    behind them before they start: the colours of the first loader task would otherwise be wiped."""
+    import time
+    nb, _ = bc7_stream(1_500_000, seed=9)                                   # 23 batches
+    of = oracle.OracleFile(nb.view())
+    hf = P.HuffmanFile(nb)
+    ctx = P.Context(0)
+    try:
+        ctx.set_image_size(640, 360)
+        ctx.stream_begin(hf.header())
+        ctx.set_async_upload(True)
+        for b0 in range(0, hf.numBatches, 8):
+            ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 8, hf.numBatches))])
+        t0 = time.time()
+        while ctx.batches_resident < hf.numBatches:
+            assert time.time() - t0 < 30.0, "loader stream made no progress"
+            time.sleep(0.001)
+        assert ctx.stream_color_format() == 7
+        p = scenes.with_flags(scenes.cameras(640, 360)["overview"], lod_percent=100)
+        ctx.clear(); ctx.render_hqs_depth(p); ctx.render_hqs_color(p); ctx.resolve_hqs(p)
+        hfb, _ = of.render_hqs_depth(p)
+        org, oba, _ = of.render_hqs_color(p, hfb)
+        rg, ba = ctx.read_accum(full=True)
+        assert np.array_equal(ctx.read_framebuffer(full=True), hfb)
+        assert np.array_equal(rg, org) and np.array_equal(ba, oba)
+        assert np.array_equal(ctx.read_rgba(), oracle.resolve_hqs(p, hfb, org, oba))
+    finally:
+        ctx.set_async_upload(False)
+        ctx.close()

@@ -33,8 +33,12 @@ def dist_lib():
     lib.pcr_dist_destroy.restype = None
     for n in ("pcr_dist_merge_min", "pcr_dist_merge_sum"):
         getattr(lib, n).argtypes = [C.c_void_p, C.c_int]
-    for n in ("pcr_dist_frame_basic", "pcr_dist_frame_hqs"):
+    for n in ("pcr_dist_frame_basic", "pcr_dist_frame_hqs", "pcr_dist_step_basic"):
         getattr(lib, n).argtypes = [C.c_void_p, C.POINTER(P.RenderParams), C.c_int]
+    lib.pcr_dist_slice_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.pcr_dist_slice_range.restype = None
+    lib.pcr_dist_set_exchange.argtypes = [C.c_void_p, C.c_int]
+    lib.pcr_dist_exchange.argtypes = [C.c_void_p]
     return lib
 
 
@@ -58,6 +62,59 @@ def test_shard_range_is_the_transport_layers_split(units, world):
         assert a.value == covered
         covered += b.value
     assert covered == units
+
+
+@pytest.mark.parametrize("elems,world", [(1920 * 1081 + 1, 8), (4096 * 4097 + 1, 8), (640 * 361 + 1, 3), (1001, 1), (10, 7), (16_781_313, 128)])
+def test_slice_range_is_the_transport_layers_slicing(elems, world):
+    """Equal, 16-byte aligned slices that cover the frame and stay inside its pad (include/pcr_types.h: PCR_FRAME_PAD_ELEMS)."""
+    lib = dist_lib()
+    S = pdist.slice_elems(elems, world)
+    for rank in range(world):
+        a, b = C.c_size_t(), C.c_size_t()
+        lib.pcr_dist_slice_range(elems, world, rank, C.byref(a), C.byref(b))
+        assert (a.value, b.value) == (rank * S, S)
+    assert S % 2 == 0 and elems <= world * S <= elems + 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", [2, 3])                 # PCR_DIST_EXCHANGE_SLICED, _SLICED_P2P
+def test_one_rank_communicator_sliced_frames_match_the_oracle(exchange):
+    """The sliced exchange on the one rank a test box has: reduce-scatter (or all-to-all + local min) over one slice that
+    reaches into the frame's pad, resolve of the own slice, gather of the image; basic (frame and steady-state step) and HQS."""
+    lib = dist_lib()
+    image, _ = scenes.synth_stream(2_000_000)
+    of = oracle.OracleFile(image.view())
+    W, H = 640, 360                                            # 640 * 361 + 1 words: odd, the slice is one word longer
+    p = scenes.with_flags(scenes.cameras(W, H)["closeup"], lod_percent=100, cull=1)
+    r = P.Renderer(W, H, device=0)
+    d = C.c_void_p()
+    try:
+        P.HuffmanLasData.create(image).load_all(r)
+        ident = C.create_string_buffer(128)
+        assert lib.pcr_dist_unique_id(ident) == 0, lib.pcr_dist_last_error()
+        assert lib.pcr_dist_create(r.ctx.h, ident, 0, 1, C.byref(d)) == 0, lib.pcr_dist_last_error()
+        assert lib.pcr_dist_exchange(d) == 1                   # AUTO on one rank: the whole-frame reduce
+        assert lib.pcr_dist_set_exchange(d, exchange) == 0 and lib.pcr_dist_exchange(d) == exchange
+        ofb, ost = of.render_basic(p)
+        want = oracle.resolve_basic(p, ofb)
+        for root in (0, -1):
+            assert lib.pcr_dist_frame_basic(d, C.byref(p), root) == 0, lib.pcr_dist_last_error()
+            assert np.array_equal(r.ctx.read_rgba(), want) and r.ctx.stats() == ost
+        r.ctx.frame_begin(p)
+        for _ in range(2):
+            assert lib.pcr_dist_step_basic(d, C.byref(p), 0) == 0, lib.pcr_dist_last_error()
+            assert np.array_equal(r.ctx.read_rgba(), want) and r.ctx.stats() == ost
+        hfb, _ = of.render_hqs_depth(p)
+        org, oba, _ = of.render_hqs_color(p, hfb)
+        for root in (0, -1):
+            assert lib.pcr_dist_frame_hqs(d, C.byref(p), root) == 0, lib.pcr_dist_last_error()
+            assert np.array_equal(r.ctx.read_framebuffer(full=True), hfb)
+            assert np.array_equal(r.ctx.read_rgba(), oracle.resolve_hqs(p, hfb, org, oba))
+        assert lib.pcr_dist_set_exchange(d, 9) != 0
+    finally:
+        if d.value:
+            lib.pcr_dist_destroy(d)
+        r.ctx.close()
 
 
 @pytest.mark.gpu
@@ -115,9 +172,25 @@ def test_render_dist_cli_prints_the_single_gpu_hash(tmp_path, method):
     assert many.returncode == 0, many.stderr
     a, b = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(many.stdout.strip().splitlines()[-1])
     assert b["ranks"] == 1 and b["batches"] == a["batches"] == 31
-    assert a["fb_fnv1a"] == b["fb_fnv1a"] and a["points_iterated"] == b["points_iterated"] and a["covered_pixels"] == b["covered_pixels"]
-    # two ranks cannot share this box's one GPU: the library says so instead of hanging in RCCL
-    two = subprocess.run([build.RENDER_DIST_BIN, *common, "--ranks", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    same = ("fb_fnv1a", "rgba_fnv1a", "points_iterated", "covered_pixels")
+    assert all(a[k] == b[k] for k in same), (a, b)
+    for merge in ("sliced", "sliced_p2p"):                      # the image assembled from the slices is the one-GPU image
+        sl = subprocess.run([build.RENDER_DIST_BIN, *common, "--ranks", "1", "--frames", "3", "--merge", merge], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert sl.returncode == 0, sl.stderr
+        c = json.loads(sl.stdout.strip().splitlines()[-1])
+        assert c["rgba_fnv1a"] == a["rgba_fnv1a"] and c["points_iterated"] == a["points_iterated"] and c["covered_pixels"] == a["covered_pixels"], (merge, a, c)
     import torch
-    if torch.cuda.device_count() < 2:
-        assert two.returncode != 0 and "pcr_create" in two.stderr
+    ngpu = torch.cuda.device_count()
+    for extra in ([], ["--allreduce"], ["--merge", "sliced"], ["--merge", "sliced_p2p"], ["--merge", "sliced", "--allreduce"]):
+        two = subprocess.run([build.RENDER_DIST_BIN, *common, "--ranks", "2", "--frames", "3", *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        if ngpu < 2:
+            # two ranks cannot share this box's one GPU: the library says so instead of hanging in RCCL
+            assert two.returncode != 0 and "pcr_create" in two.stderr
+            break
+        # a box with peers: every exchange form merges the two shards into the one-GPU frame, bit for bit
+        assert two.returncode == 0, (extra, two.stderr)
+        c = json.loads(two.stdout.strip().splitlines()[-1])
+        assert c["ranks"] == 2 and c["rgba_fnv1a"] == a["rgba_fnv1a"], (extra, a, c)
+        assert c["points_iterated"] == a["points_iterated"] and c["covered_pixels"] == a["covered_pixels"], (extra, a, c)
+        if "--merge" not in extra:
+            assert c["fb_fnv1a"] == a["fb_fnv1a"], (extra, a, c)

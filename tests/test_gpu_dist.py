@@ -1,5 +1,5 @@
 """The multi-GPU code path on the one GPU a test box has: a single-rank RCCL group, torch-owned int64-mergeable
-framebuffers (DeviceFrame), the one-stream sharded forms and the pipelined renderer, against the oracle. The N > 1
+framebuffers (DeviceFrame / SlicedFrame) and the one-stream sharded forms, against the oracle. The N > 1
 arithmetic (shard ranges, head exchange, min/sum merges) is covered with gloo in tests/test_dist_cpu.py."""
 import os
 
@@ -75,31 +75,6 @@ def test_sharded_forms_on_a_single_rank_group(group, loaded, merge):
     assert np.array_equal(ctx.read_framebuffer(full=True), of.render_basic(p)[0])
 
 
-def test_pipelined_renderer_frames(group, loaded):
-    ctx, of = loaded
-    cams = scenes.cameras(W, H)
-    pipe = pdist.PipelinedBasicRenderer(ctx, W, H, group, merge="reduce")
-    try:
-        seq = [scenes.with_flags(cams[name], lod_percent=lod, cull=cull)
-               for name, lod, cull in (("overview", 100, 0), ("closeup", 10, 1), ("overview", 10, 1), ("closeup", 100, 0))]
-        for p in seq:
-            pipe.step(p)
-            pipe.finish()
-            f = pipe.last_frame()
-            f.bind()
-            ofb, _ = of.render_basic(p)
-            assert np.array_equal(ctx.read_framebuffer(full=True), ofb)
-            assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(p, ofb))
-        # back-to-back frames without a fence in between: the last one is what the buffers hold
-        for p in seq:
-            pipe.step(p)
-        pipe.finish()
-        pipe.last_frame().bind()
-        assert np.array_equal(ctx.read_framebuffer(full=True), of.render_basic(seq[-1])[0])
-    finally:
-        pipe.release()
-
-
 def test_slice_kernels_against_numpy(group, loaded):
     """pcr_merge_min_slices / pcr_resolve_basic_range on their own: three slices of random keys (empty = INT64_MAX)."""
     import torch
@@ -130,14 +105,14 @@ def test_slice_kernels_against_numpy(group, loaded):
         ctx.set_stream(0)
 
 
-def test_all_to_all_form_on_a_single_rank_group(group, loaded):
+def test_sliced_form_on_a_single_rank_group(group, loaded):
     import torch
     ctx, of = loaded
     p = scenes.with_flags(scenes.cameras(W, H)["closeup"], lod_percent=100, cull=1)
     frame = pdist.SlicedFrame(ctx, W, H, group, 1)
     try:
         frame.bind()
-        pdist.render_basic_sharded(ctx, frame, p, 1, merge="a2a")
+        pdist.render_basic_sharded(ctx, frame, p, 1, merge="sliced")
         torch.cuda.synchronize()
         ofb, _ = of.render_basic(p)
         merged = frame.gather_merged_framebuffer().cpu().numpy()
@@ -146,17 +121,3 @@ def test_all_to_all_form_on_a_single_rank_group(group, loaded):
         assert np.array_equal(frame.image().cpu().numpy().view(np.uint32)[:want.size], want)
     finally:
         frame.release()
-    pipe = pdist.PipelinedBasicRenderer(ctx, W, H, group, merge="a2a")
-    try:
-        cams = scenes.cameras(W, H)
-        seq = [scenes.with_flags(cams[name], lod_percent=lod, cull=cull) for name, lod, cull in (("overview", 100, 0), ("closeup", 10, 1), ("inside", 100, 1))]
-        for q in seq:
-            pipe.step(q)
-        pipe.finish()
-        want = oracle.resolve_basic(seq[-1], of.render_basic(seq[-1])[0]).ravel()
-        assert np.array_equal(pipe.last_frame().image().cpu().numpy().view(np.uint32)[:want.size], want)
-        # and the frame before it is still intact in the other buffer
-        want = oracle.resolve_basic(seq[-2], of.render_basic(seq[-2])[0]).ravel()
-        assert np.array_equal(pipe.frames[pipe.k & 1].image().cpu().numpy().view(np.uint32)[:want.size], want)
-    finally:
-        pipe.release()

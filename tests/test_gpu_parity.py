@@ -398,3 +398,38 @@ def test_frame_turn_equals_resolve_then_frame_begin(renderer, stream2m):
     assert not rg.any() and not ba.any()
     ctx.render_basic(p)
     assert np.array_equal(ctx.read_framebuffer(full=True), of.render_basic(p)[0])
+
+
+def test_hqs_colour_pass_reuses_the_depth_passes_prepass_only_for_the_same_frame(renderer, stream2m):
+    """One cull/LOD prepass per HQS frame: the depth pass's prepass (run by pcr_frame_begin / pcr_frame_turn or by the pass
+    itself) also writes the colour pass's LDS window plan, and the colour pass skips its own when it is handed the same
+    parameters. With other parameters -- another level of detail, another camera -- it has to run its own: both against the
+    oracle, on a 140 KiB-window frame size too (the window plan depends on the dynamic LDS size)."""
+    nb, of = stream2m
+    ctx = renderer.ctx
+    _load(renderer, nb)
+    cams = scenes.cameras(W, H)
+    p = scenes.with_flags(cams["closeup"], lod_percent=100, cull=1)
+    other = (scenes.with_flags(cams["closeup"], lod_percent=10, cull=1), scenes.with_flags(cams["overview"], lod_percent=100, cull=0))
+    hfb, hst = of.render_hqs_depth(p)
+    for begin in ("clear", "frame_begin", "frame_turn"):
+        for q in (p,) + other:
+            if begin == "clear":
+                ctx.clear()
+            elif begin == "frame_begin":
+                ctx.frame_begin(p, hqs=True)
+            else:
+                ctx.frame_begin(other[1], hqs=True); ctx.render_hqs_depth(other[1]); ctx.render_hqs_color(other[1])
+                ctx.frame_turn(other[1], p, hqs=True)
+            ctx.render_hqs_depth(p)
+            assert ctx.stats() == hst and np.array_equal(ctx.read_framebuffer(full=True), hfb), (begin,)
+            ctx.render_hqs_color(q)
+            org, oba, ost = of.render_hqs_color(q, hfb)
+            rg, ba = ctx.read_accum(full=True)
+            assert ctx.stats() == ost, (begin, q.lod_percent)
+            assert np.array_equal(rg, org) and np.array_equal(ba, oba), (begin, q.lod_percent)
+    # a second colour pass over the same depth buffer adds the same sums once more (nothing stale is reused)
+    ctx.clear(); ctx.render_hqs_depth(p); ctx.render_hqs_color(p); ctx.render_hqs_color(p)
+    org, oba, _ = of.render_hqs_color(p, hfb)
+    rg, ba = ctx.read_accum(full=True)
+    assert np.array_equal(rg, 2 * org) and np.array_equal(ba, 2 * oba)
