@@ -64,6 +64,7 @@ def parse_args():
                     help="N > 1: who calls RCCL. torch (default until the C++ layer has met a peer on hardware): torch.distributed "
                          "collectives on torch-owned int64 frames; rccl = the C++ layer (include/pcr_dist.h: ncclUint64 min in place on "
                          "the context's stream); auto = rccl after one frame of each has produced the same merged image on rank 0, torch otherwise")
+    ap.add_argument("--batches", type=int, default=0, help="experiments: load only the first N batches of this rank's shard")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the second pass with the other stream layout")
@@ -160,6 +161,8 @@ def main():
     t_gen = time.time() - t0
     hf = P.HuffmanFile(image)
     local_first = first_b - c0 * (CHUNK // BATCH)
+    if args.batches:
+        count_b = min(count_b, args.batches)
     has_follower = first_b + count_b < nb_total
 
     ctx = P.Context(local_rank)

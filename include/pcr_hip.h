@@ -36,8 +36,9 @@ typedef struct pcr_ctx pcr_ctx;
 int         pcr_create(int device, pcr_ctx **out);
 void        pcr_destroy(pcr_ctx *ctx);
 const char *pcr_last_error(const pcr_ctx *ctx);
-/* Borrow an existing HIP stream (hipStream_t) instead of the context's own; NULL restores it. Does not
- * synchronise: calls made afterwards are enqueued on the new stream, ordering against work already enqueued on the
+/* Borrow an existing HIP stream (hipStream_t) instead of the context's own; NULL restores it (so the legacy default
+ * stream, whose handle is NULL, cannot be borrowed: a caller that works on it has to create a stream and move there). Does
+ * not synchronise: calls made afterwards are enqueued on the new stream, ordering against work already enqueued on the
  * previous one is the caller's (HIP events). */
 int         pcr_set_stream(pcr_ctx *ctx, void *hip_stream);
 int         pcr_synchronize(pcr_ctx *ctx);

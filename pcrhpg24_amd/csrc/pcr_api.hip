@@ -52,7 +52,7 @@ struct pcr_ctx {
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
     // dense lists of the batches a frame draws, compacted by k_lod_prepass per workgroup (see RenderArgs): d_order[2][order_stride],
     // d_chunk_count[2][PCR_MAX_PREPASS_WORKGROUPS]
-    uint32_t *d_order = nullptr;
+    DrawRec *d_order = nullptr;
     uint32_t *d_chunk_count = nullptr;
     uint32_t order_stride = 0;
     // "some batch of this stream was ever flagged BF_GENERIC_SLOW_PATH": set on the device by k_transcode, copied to a
@@ -175,6 +175,7 @@ void free_stream_buffers(pcr_ctx *c)
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_colors_t); dfree(c->d_lod); dfree(c->d_win);
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); dfree(c->d_batch_runs); c->transcoded = 0;
     dfree(c->d_order); dfree(c->d_chunk_count); dfree(c->d_any_generic); c->order_stride = 0;
+
     if (c->any_generic_pending && c->any_generic_ev) (void)hipEventSynchronize(c->any_generic_ev);
     c->any_generic_pending = false;
     if (c->h_any_generic) *c->h_any_generic = 0;
@@ -1356,6 +1357,23 @@ int pcr_kernel_timing_read(pcr_ctx *c, float *avg_ms, int *launches)
     *avg_ms = (float)(sum / n); *launches = n;
     return PCR_OK;
 }
+
+#ifdef PCR_EXP_TIMELINE
+int pcr_exp_read_timeline(pcr_ctx *c, unsigned long long *out, size_t n)
+{
+    if (!c || !out) return PCR_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_timeline), n * sizeof(unsigned long long)));
+    return PCR_OK;
+}
+int pcr_exp_read_wave_ends(pcr_ctx *c, unsigned long long *out, size_t n)
+{
+    if (!c || !out) return PCR_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_wave_end), n * sizeof(unsigned long long)));
+    return PCR_OK;
+}
+#endif
 
 } // extern "C"
 

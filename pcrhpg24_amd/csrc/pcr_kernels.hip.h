@@ -65,7 +65,8 @@ __device__ __forceinline__ uint32_t esc_pool_bytes(uint32_t pool_words) { return
 // pixels the batch's LDS window can hold next to its escape pool
 __device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_bytes, uint32_t dyn_lds_bytes)
 {
-    return (int)((dyn_lds_bytes - esc_pool_bytes(esc_pool_words(esc_total))) / (uint32_t)pixel_bytes);
+    // (one pixel less than fits: the slot behind the last window pixel is k_render's dummy slot, see there)
+    return (int)((dyn_lds_bytes - esc_pool_bytes(esc_pool_words(esc_total))) / (uint32_t)pixel_bytes) - 1;
 }
 
 // Lane-major copy of the word stream (k_transcode): row r holds the r-th word each of the batch's 1024 chains consumes.
@@ -127,6 +128,8 @@ struct StreamView {
     int64_t batch_index_base;
 };
 
+struct DrawRec { uint32_t b, lod, esc_total, reserved; int64_t sep_off; int64_t reserved2; };     // 32 bytes
+
 struct FrameView {
     uint64_t *fb;
     uint64_t *rg;
@@ -168,9 +171,15 @@ struct RenderArgs {
     // checked variant of the kernel). No atomics, nothing to zero between frames. (A first version appended the chunks
     // with one atomic per workgroup: the chunks then land in arrival order, and the close-up frame, whose heavy batches
     // lead the file, ran 25 % longer with them shuffled.)
-    uint32_t *order;          // [2][order_stride]
+    struct DrawRec *order;    // [2][order_stride]
     uint32_t *chunk_count;    // [2][PCR_MAX_PREPASS_WORKGROUPS]
     uint32_t order_stride;    // prepass workgroups * PREPASS_BATCHES
+    // A list entry is a record, not just the batch's index: what k_render's workgroup needs to know before it can request the
+    // batch's data (level-of-detail word, escape count, escape offset). Its set-up is then three dependent memory levels (chunk
+    // counts -> record -> data) instead of four (... -> list entry -> lod / batch header / escape count -> data): 7 us of a
+    // workgroup's 61 us life, spent with its sixteen wave slots idle (profiles/r03_experiments.md). (A fourth step -- the prepass
+    // workgroup that finishes last moves the records into one dense array, so that workgroup x starts from ONE load -- was built
+    // and measured: k_render -2 %, but 9 us more on the critical path of the launch that carries the prepass. Dropped.)
     int variant_hqs;          // LOD expression variant
     int win_pixel_bytes;      // what a window pixel of the following k_render<MODE> takes in LDS (WIN_PIXEL_BYTES*)
     uint32_t dyn_lds_bytes;   // dynamic LDS of the following k_render launch: DYN_LDS_BYTES or DYN_LDS_BYTES_BIG
@@ -248,13 +257,19 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
     if (threadIdx.x < 64) {
         const uint32_t kind = threadIdx.x < PREPASS_BATCHES ? s_kind[threadIdx.x] : 0u;
         const uint64_t below = (1ull << threadIdx.x) - 1ull;
+        // (the list entry is the whole record k_render's workgroup starts from, see RenderArgs::order)
+        DrawRec r = {0, 0, 0, 0, 0, 0};
+        if (kind) {
+            const uint32_t bb = block * PREPASS_BATCHES + threadIdx.x;
+            r.b = bb; r.lod = a.lod[bb];
+            r.esc_total = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 1023];
+            r.sep_off = a.s.batches[bb].separate_batch_offset;
+        }
 #pragma unroll
         for (uint32_t k = 1; k <= 2; ++k) {
             const uint64_t m = __ballot(kind == k);
             if (threadIdx.x == 0) a.chunk_count[(k - 1) * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
-            if (kind == k)
-                a.order[(size_t)(k - 1) * a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] =
-                    block * PREPASS_BATCHES + threadIdx.x;
+            if (kind == k) a.order[(size_t)(k - 1) * a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
         }
     }
     // LDS framebuffer windows of the batches that draw: RUNS lanes per batch, one per run of chains
@@ -822,6 +837,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_bounds(StreamView s, con
     if (tid < RUNS * 6) out[4 + tid] = __float_as_uint(float_unorder(s_box[tid / 6][tid % 6]));
 }
 
+#ifdef PCR_EXP_TIMELINE   /* experiment: per-workgroup time stamps of k_render's phases (100 MHz wall clock) + the hardware slot it ran on */
+__device__ unsigned long long g_timeline[8192 * 8];
+__device__ unsigned long long g_wave_end[8192 * 16];        // per wave: wall clock at the end of its point loop
+#define PCR_TL(slot) do { if (threadIdx.x == 0) g_timeline[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PCR_TL(slot) do { } while (0)
+#endif
+
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -835,7 +858,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     constexpr bool COLOR_PASS = MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7, BC7 = MODE == MODE_HQS_COLOR_BC7;
     // second level of the compaction: which batch is the blockIdx.x-th of my list? Every wave works it out for itself (a
     // 64-lane inclusive prefix sum over the chunk counts, 64 chunks = 2048 batches per round): no barrier, no LDS.
-    uint32_t b;
+    PCR_TL(0);
+#ifdef PCR_EXP_TIMELINE
+    if (threadIdx.x == 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_timeline[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
+    // second level of the compaction: which batch is the blockIdx.x-th of my list? Every wave works it out for itself (a
+    // 64-lane inclusive prefix sum over the chunk counts, 64 chunks = 2048 batches per round): no barrier, no LDS.
+    DrawRec rec;
     {
         const uint32_t lane = threadIdx.x & 63u, chunks = a.order_stride / PREPASS_BATCHES;
         const uint32_t *cc = a.chunk_count + (GENERIC ? PCR_MAX_PREPASS_WORKGROUPS : 0);
@@ -858,11 +893,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             }
             before += total;
         }
-        found = __builtin_amdgcn_readfirstlane(found);                      // (the same in every lane: keep it, and the batch index, scalar)
+        found = __builtin_amdgcn_readfirstlane(found);                      // (the same in every lane: keep it, and the record, scalar)
         if (found == 0xFFFFFFFFu) return;                                   // the grid is sized for "every batch visible"
-        b = a.order[(GENERIC ? (size_t)a.order_stride : 0) + found];
+        rec = a.order[(GENERIC ? (size_t)a.order_stride : 0) + found];
     }
-    const uint32_t lod = a.lod[b];
+    const uint32_t b = rec.b;
+    const uint32_t lod = rec.lod;
     const int npr = (int)(lod & LOD_NPR_MASK);
     const bool use_double = (lod & LOD_DOUBLE) != 0;
     const uint32_t tid = threadIdx.x;
@@ -883,7 +919,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     reinterpret_cast<uint4 *>(s_table)[tid] = reinterpret_cast<const uint4 *>(a.s.packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
 
     const pcr_gpu_batch *gb = a.s.batches + b;
-    const int64_t sep_off = gb->separate_batch_offset;      // :405
+    const int64_t sep_off = rec.sep_off;                    // :405
     const int32_t *sep = a.s.separate + sep_off;            // batch-relative base (uniform)
     // Reads past the logical end of the escape stream (zero pad included) are defined as 0. The allocation carries
     // PCR_GUARD_WORDS extra zero words that nothing ever writes, so clamping the index to the guard is enough:
@@ -893,7 +929,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     // ---- escape words of the batch -> LDS (all of them, or none) --------------------------------------------
     const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
-    const uint32_t esc_total = (uint32_t)ssz[1023];
+    const uint32_t esc_total = rec.esc_total;
     // The pool also takes ESC_SLACK words that FOLLOW the batch's own escapes in memory, so that the reference's
     // tail over-reads find in LDS what they would find in global memory; reads beyond even that, and
     // batches that do not fit, go to global memory (slow variant of the decode step).
@@ -962,6 +998,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     };
     if (!COLOR_PASS) {
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) s_win[i] = ~0ull;
+        // The dummy slot, behind the last window pixel: the window word of every point that has none -- outside the frustum, or
+        // inside it but outside its window. It starts as 0, so the depth pre-filter below turns such a lane away without a mask
+        // for "the pending point is valid" having to be kept (an off-window point's word is replaced by the global one; what its
+        // LDS atomic then leaves in the slot is a depth no smaller than any real one there: harmless, and never merged).
+        if (tid == 0) s_win[wpix] = 0ull;
     } else {
         // colour pass: the depths of the rectangles as the depth pass left them, sums zeroed
         for_window_pixels([&](uint32_t i, size_t gp) {
@@ -1083,6 +1124,21 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         else      atomicMin((unsigned long long *)&g_fb[pix], key);         // :300
     };
 
+    // Basic / depth pass: the same for a pending point described without per-lane flags. Its window word `wp` is the dummy slot
+    // unless the point lies in its window; `old` is that word, or the global framebuffer word for the lanes of `off_mask`
+    // (inside the frustum, outside the window). A lane with nothing pending holds a dummy word of depth 0 and fails the filter.
+    // Scalar instructions are not free here (+16 of them per point: +6 % kernel time, profiles/r03_experiments.md): lane masks
+    // carried as 64-bit values and tested as such cost a compare and a branch, bools carried across the loop cost three
+    // mask merges each.
+    auto scatter_min = [&](__attribute__((address_space(3))) unsigned long long *wp, uint32_t depth, uint64_t old, uint64_t off_mask, uint32_t pix, int point) __attribute__((always_inline)) {
+        // pre-read filter (:297-298) on the depth half only: the result is min(depth<<32|payload) over all inside points
+        // whatever passes it (min is idempotent), so ties go to the atomic instead of a 64-bit compare here
+        if (depth > (uint32_t)(old >> 32)) return;
+        const unsigned long long key = ((unsigned long long)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload);   // :299 / depth.cu:139-145
+        __hip_atomic_fetch_min(wp, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_inverse_ballot_w64(off_mask)) atomicMin((unsigned long long *)&g_fb[pix], key);   // :300 (rare)
+    };
+
     // End of a point: SFT0 - sft bits were consumed. Retire the 0..2 words that ran dry, pull in far0/far1 (requested a
     // whole point ago), request the next two, cut the next view. u = spare - consumed + 64 lies in [28, 95].
 #define PCR_ADVANCE_WORD_WINDOW()                                                          \
@@ -1108,10 +1164,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         sft = SFT0;                                                                        \
     } while (0)
 
-    bool pend_valid = false, pend_off = false;
+    bool pend_valid = false, pend_off = false;              // (colour pass)
+    uint64_t pend_off_mask = 0;                             // basic / depth pass: lanes whose pending point is inside the frustum but outside its window
     uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
-    unsigned long long *const s_win_mine = s_win + wbase;   // my wave's window
-    unsigned long long *pend_p = s_win;                     // basic / depth pass: the pending point's word in the LDS window
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    lds_u64 *const s_win_mine = (lds_u64 *)(s_win + wbase); // my run's window
+    lds_u64 *const s_dummy = (lds_u64 *)(s_win + wpix);     // (see the window's set-up)
+    const uint32_t dummy_idx = wpix - wbase;                // ... as an index into my run's window
+    lds_u64 *pend_p = s_dummy;                              // basic / depth pass: the pending point's word in the LDS window
     uint64_t pend_old = 0;
 
     const float *M = a.p.transform;
@@ -1127,7 +1187,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const float m30 = in_vgpr_f(M[12]), m31 = in_vgpr_f(M[13]), m32 = in_vgpr_f(M[14]), m33 = in_vgpr_f(M[15]);   // the w row
     const uint32_t v_wx0 = wx0, v_wy0 = wy0;                // (per-lane values: in vector registers anyway)
 
+    PCR_TL(1);
     __syncthreads();        // table, escapes and window are visible
+    PCR_TL(2);
 
 #ifdef PCR_EXP_PROLOGUE_ONLY   /* experiment only: cost of the per-batch set-up and the window merge (results are wrong) */
     const int npr_run = a.p.reserved == 12345 ? npr : 0;
@@ -1204,11 +1266,27 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         return val;
     };
 
+#if defined(PCR_EXP_PRIO_WAVE)   /* experiment: the hardware issues oldest-first; give a workgroup's later waves the higher priority */
+    switch ((tid >> 8) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
     for (int seg = 0; seg < npr_run; seg += 16) {
+#if defined(PCR_EXP_PRIO_SEG)    /* experiment: a wave that is behind (an earlier segment) goes first */
+      switch (seg >> 4) {
+          case 0: __builtin_amdgcn_s_setprio(3); break;
+          case 1: __builtin_amdgcn_s_setprio(2); break;
+          case 2: __builtin_amdgcn_s_setprio(1); break;
+          default: __builtin_amdgcn_s_setprio(0); break;
+      }
+#endif
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
-      scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, seg - 1);
-      pend_valid = false;
+      if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, seg - 1); pend_valid = false; }
+      else { scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, seg - 1); pend_p = s_dummy; pend_old = 0; pend_off_mask = 0; }
       if (MODE != MODE_HQS_DEPTH) {
           if (BC7) pal7 = bc7_block(blocks7[(seg >> 4) * PCR_WORKGROUP_SIZE]);
           else {
@@ -1226,6 +1304,25 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             lwo += PW_HI_ROW_BYTES; lwo2 += PW_LO_ROW_BYTES;
             fetched_hi = pw_load_hi(lwo); fetched_lo = pw_load_lo(lwo2);
         }
+#if defined(PCR_EXP_PAD_FAST) || defined(PCR_EXP_PAD_SLOW) || defined(PCR_EXP_PAD_SALU)   /* experiment: what one more instruction per point costs */
+        {
+            uint32_t pad = tid;
+            (void)pad;
+#ifdef PCR_EXP_PAD_FAST
+#pragma unroll
+            for (int k = 0; k < PCR_EXP_PAD_FAST; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
+#endif
+#ifdef PCR_EXP_PAD_SLOW
+#pragma unroll
+            for (int k = 0; k < PCR_EXP_PAD_SLOW; ++k) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(pad));
+#endif
+#ifdef PCR_EXP_PAD_SALU
+            uint32_t spad = (uint32_t)i;
+#pragma unroll
+            for (int k = 0; k < PCR_EXP_PAD_SALU; ++k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(spad));
+#endif
+        }
+#endif
 #ifdef PCR_EXP_EXTRA_LOAD   /* experiment: 4 (or 8) more bytes of HBM traffic per point, consumed at the end of the point */
         const uint32_t extra0 = lw_load((uint32_t)i * LW_ROW_BYTES + tid * 4);
 #if PCR_EXP_EXTRA_LOAD > 1
@@ -1248,7 +1345,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
             // word has been in flight since the end of the last iteration
             // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
-            if (!COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+            if (!COLOR_PASS) scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, i - 1);
             sft -= e1;
             const uint32_t toff2 = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
             const uint32_t e2 = table_entry(toff2);
@@ -1258,11 +1355,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             constexpr std::integral_constant<bool, false> table_first{};
             constexpr std::integral_constant<bool, true> escape_first{};
             d0 = symbol_step(table_first);                                  // :430
-            if (!COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+            if (!COLOR_PASS) scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, i - 1);
             d1 = symbol_step(table_first);
             d2 = symbol_step(escape_first);
         }
-        if (COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, i - 1);
+        if (COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
         pz = (int32_t)((uint32_t)pz + d2);
@@ -1276,7 +1373,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         // projection is carried into the next iteration -- with ix / iy declared outside, every iteration copied them)
         float fx, fy, fz;
         float qx, qy, qw;
-        bool candidate, w_ok, inside;
+        bool inside;
+        uint64_t cand_mask;                 // lanes whose point is inside the frustum, as a 64-bit lane mask (a scalar register pair)
         int ix, iy;
         // first half of rasterize() (:278-287), part 1: the three dot products and the inside test without dividing. For finite
         // w > 0 the correctly rounded quotient RN(x/w) lies in [-1,1] exactly when |x| <= w (if x > w then x/w >= 1 + ulp(w)/w >
@@ -1285,8 +1383,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             qx = __fmaf_rn(m03, 1.0f, __fmaf_rn(m02, fz, __fmaf_rn(m01, fy, m00 * fx)));       // dot4(M + 0, ...)
             qy = __fmaf_rn(m13, 1.0f, __fmaf_rn(m12, fz, __fmaf_rn(m11, fy, m10 * fx)));       // dot4(M + 4, ...)
             qw = __fmaf_rn(m33, 1.0f, __fmaf_rn(m32, fz, __fmaf_rn(m31, fy, m30 * fx)));       // dot4(M + 12, ...), operands in VGPRs
-            candidate = fabsf(qx) <= qw && fabsf(qy) <= qw;
-            w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;           // 2^-64 <= w < 2^64
+            // (lane masks as 64-bit scalars: a ballot of a compare IS the compare's result register, mask logic is one scalar
+            // instruction each, and nothing is merged where control flow joins)
+            cand_mask = __builtin_amdgcn_ballot_w64(fabsf(qx) <= qw) & __builtin_amdgcn_ballot_w64(fabsf(qy) <= qw);
         };
         // part 2: the division and the pixel (:279-285). The division is the IEEE sequence hipcc emits for `/` with its range
         // scaling removed, shared reciprocal, x and y packed; it is bit-identical to `/` for w in [2^-64, 2^64) (no intermediate
@@ -1296,13 +1395,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             // (both forms run for every lane, candidate or not -- a lane that is not one produces a pixel nobody looks at: the
             // instructions issue for the wave anyway, and with ix / iy written on every path hipcc neither masks the block nor
             // carries last iteration's pixel along for the lanes that skipped it)
-            if (__builtin_expect(__any(candidate && !w_ok), 0)) {
-                const float nx = qx / qw, ny = qy / qw;
-                ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);                 // :283-284
-                iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
-                inside = qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f      // NaN-rejecting (Appendix C.2)
-                         && (uint32_t)(ix + iy * img_w) < fb_elems;         // :285
-            } else {
+            {
                 const float r0 = __builtin_amdgcn_rcpf(qw);
                 const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
                 const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
@@ -1312,52 +1405,73 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 const v2f half = {0.5f, 0.5f}, size = {fw, fh};
                 const v2f img = __builtin_elementwise_fma(q2, half, half) * size;       // :283
                 ix = (int)img.x; iy = (int)img.y;                                       // :284 (a candidate's pixel index is always < fb_elems here)
-                inside = candidate;
             }
+            // (the plain `/` as an override behind the fast form, not as its `else`: an if / else of a uniform condition costs the
+            // common path two branches and three scalar instructions here, an `if` alone one of each)
+            const uint64_t w_ok_mask = __builtin_amdgcn_ballot_w64((__float_as_uint(qw) - 0x1F800000u) < 0x40000000u);   // 2^-64 <= w < 2^64
+            if (__builtin_expect((cand_mask & ~w_ok_mask) != 0, 0)) {
+                const float nx = qx / qw, ny = qy / qw;
+                ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);                 // :283-284
+                iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+                // (inside <=> candidate here as well: for w > 0 the correctly rounded quotient lies in [-1,1] exactly when |x| <= w,
+                // a NaN or w <= 0 fails both forms, and a pixel of a point inside is below fb_elems -- Appendix C.2)
+            }
+            inside = __builtin_amdgcn_inverse_ballot_w64(cand_mask);
         };
         // part 3: the point becomes the pending one; its framebuffer word is requested now and consumed an iteration later:
         // from the LDS window if the pixel lies in the batch's rectangle (nearly always), from global memory otherwise (:297)
         auto project_request = [&]() __attribute__((always_inline)) {
+            if (!COLOR_PASS) {
+                // No flags per lane, no block under `if (inside)`: every lane works out a window position (garbage for a lane that is
+                // not inside), the masks decide. The window word is read by EVERY lane (the dummy slot's if it has none): with the
+                // read issued on every path hipcc knows how many LDS results are outstanding at the top of the next iteration and
+                // waits for the look-ahead table entry alone (lgkmcnt(1)) instead of for this read as well.
+                const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
+                // (bitwise: `&&` would put the two compares under a branch of their own)
+                const uint64_t in_mask = cand_mask & __builtin_amdgcn_ballot_w64(rx < ww) & __builtin_amdgcn_ballot_w64(ry < wh);
+                pend_off_mask = cand_mask & ~in_mask;
+                pend_depth = __float_as_uint(qw);                                       // :287
+                pend_p = s_win_mine + (__builtin_amdgcn_inverse_ballot_w64(in_mask) ? (uint32_t)__umul24(ry, ww) + rx : dummy_idx);
+                pend_old = *pend_p;
+                if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) {   // (rare: the window plan keeps nearly every point inside)
+                    pend_pix = (uint32_t)(ix + iy * img_w);                             // :285
+                    // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
+                    // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
+                    pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                return;
+            }
             bool in_window = false, off_window = false;
             if (inside) {
                 pend_depth = __float_as_uint(qw);                                       // :287
-                if (COLOR_PASS) pend_pix = (uint32_t)(ix + iy * img_w);     // the colour pass names its runs by pixel
+                pend_pix = (uint32_t)(ix + iy * img_w);                     // the colour pass names its runs by pixel
                 const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
                 in_window = rx < ww && ry < wh;
                 off_window = !in_window;
                 // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
-                if (COLOR_PASS) pend_w = wbase + (in_window ? ry * ww + rx : 0u); else pend_p = s_win_mine + (in_window ? ry * ww + rx : 0u);
+                pend_w = wbase + (in_window ? ry * ww + rx : 0u);
             }
             pend_valid = inside;
             pend_off = off_window;
-            // The window word is read by EVERY lane, wanted or not (a lane that is not inside re-reads its last pixel): with the
-            // read issued on every path hipcc knows how many LDS results are outstanding at the top of the next iteration and
-            // waits for the look-ahead table entry alone (lgkmcnt(1)) instead of for this read as well.
-            // (The global load comes second: a load into the same registers issued behind the LDS read only has to wait for the
-            // LDS counter, the other way round the LDS read would wait for every vector-memory load in flight.)
-            pend_old = COLOR_PASS ? (uint64_t)s_depth[pend_w] << 32 : *pend_p;
-            if (off_window) {
-                pend_pix = (uint32_t)(ix + iy * img_w);                                 // :285
-                // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
-                // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
-                pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
+            // (every lane reads, wanted or not: see above)
+            pend_old = (uint64_t)s_depth[pend_w] << 32;
+            if (off_window) pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         };
 
+        // (the float form always, the double form as an override for the batches that want it: see project_divide)
+        fx = __fmaf_rn((float)px, fsx, fox);                                // :529-531
+        fy = __fmaf_rn((float)py, fsy, foy);
+        fz = __fmaf_rn((float)pz, fsz, foz);
         if (use_double) {                                                   // :459-461
             fx = (float)__fma_rn((double)px, sx, ox);
             fy = (float)__fma_rn((double)py, sy, oy);
             fz = (float)__fma_rn((double)pz, sz, oz);
-        } else {                                                            // :529-531
-            fx = __fmaf_rn((float)px, fsx, fox);
-            fy = __fmaf_rn((float)py, fsy, foy);
-            fz = __fmaf_rn((float)pz, fsz, foz);
         }
         project_dots();                                                     // first half of rasterize() (:278-287) for point i
         project_divide();
 #ifdef PCR_EXP_NO_FBLOAD   /* experiment only: decode + projection, no framebuffer traffic (results are wrong) */
         if (inside && ix == 0x12345678) g_fb[tid] = __float_as_uint(qw);
-        pend_valid = false;
+        pend_valid = false; pend_p = s_dummy; pend_old = 0; pend_off_mask = 0;
 #else
         project_request();
 #endif
@@ -1375,13 +1489,21 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
       }
     }
-    scatter(pend_valid, pend_off, pend_pix, pend_w, pend_p, pend_depth, pend_old, npr_run - 1);
-    if (COLOR_PASS) flush_run();
+    if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, npr_run - 1); flush_run(); }
+    else scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, npr_run - 1);
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
+#if defined(PCR_EXP_PRIO_WAVE) || defined(PCR_EXP_PRIO_SEG)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef PCR_EXP_TIMELINE
+    if ((threadIdx.x & 63u) == 0) g_wave_end[(size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = wall_clock64();
+#endif
+    PCR_TL(3);
     if (wpix) {
         __syncthreads();
+        PCR_TL(4);
         for_window_pixels([&](uint32_t i, size_t gp) {
             if (COLOR_PASS) {
                 const unsigned long long vba = s_ba[i];
@@ -1396,6 +1518,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             }
         });
     }
+    PCR_TL(5);
 }
 
 // ------------------------------------------------------------------------------------------------

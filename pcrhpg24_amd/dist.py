@@ -93,6 +93,34 @@ def exchange_shard_heads(head_enc: np.ndarray, head_sep: np.ndarray, device, gro
     return (nx[2:2 + nx[0]].copy().view(np.uint32), nx[2 + ENCODED_PAD_WORDS:2 + ENCODED_PAD_WORDS + nx[1]].copy())
 
 
+def _shared_stream(frame, stream):
+    """The ONE stream the context's kernels and torch's collectives are enqueued on. torch's default stream has the handle 0,
+    which pcr_set_stream reads as "the context's own stream" -- a non-blocking stream nothing orders against torch's: the
+    collective then starts while the frame is still being drawn (found in round 3: a warmed-up RCCL launches fast enough to
+    show it). So if torch's current stream is the default one, a stream of the frame's own becomes torch's current stream
+    until release()."""
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream(frame.device)
+    frame._prev_stream = None
+    if s.cuda_stream == 0:
+        if getattr(frame, "_own_stream", None) is None:
+            frame._own_stream = torch.cuda.Stream(frame.device)
+        frame._own_stream.wait_stream(s)             # the frame's tensors were filled on the default stream
+        frame._prev_stream = s
+        torch.cuda.set_stream(frame._own_stream)
+        s = frame._own_stream
+    return s
+
+
+def _restore_stream(frame):
+    import torch
+    prev = getattr(frame, "_prev_stream", None)
+    if prev is not None:
+        prev.wait_stream(frame._own_stream)
+        torch.cuda.set_stream(prev)
+        frame._prev_stream = None
+
+
 class DeviceFrame:
     """Framebuffers owned by torch (so RCCL can reduce them in place) and lent to a pcr context."""
 
@@ -112,8 +140,7 @@ class DeviceFrame:
 
     def bind(self, stream=None):
         """Make this frame the context's render target; pcr work goes to `stream` (default: torch's current)."""
-        import torch
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        s = _shared_stream(self, stream)
         self.ctx.set_stream(s.cuda_stream)
         self.ctx.use_external_buffers(self.fb.data_ptr(), self.rg.data_ptr() if self.rg is not None else 0,
                                       self.ba.data_ptr() if self.ba is not None else 0)
@@ -145,6 +172,7 @@ class DeviceFrame:
         self.ctx.use_external_buffers(0, 0, 0)
         self.ctx.set_int64_mergeable(False)
         self.ctx.set_stream(0)
+        _restore_stream(self)
 
 
 def slice_elems(n: int, world_size: int) -> int:
@@ -184,8 +212,7 @@ class SlicedFrame:
         self.rg = self.ba = self.acc = None
 
     def bind(self, stream=None):
-        import torch
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        s = _shared_stream(self, stream)
         self.ctx.set_stream(s.cuda_stream)
         self.ctx.use_external_buffers(self.fb.data_ptr(), 0, 0)
         self.ctx.set_int64_mergeable(True)
@@ -214,6 +241,7 @@ class SlicedFrame:
         self.ctx.use_external_buffers(0, 0, 0)
         self.ctx.set_int64_mergeable(False)
         self.ctx.set_stream(0)
+        _restore_stream(self)
 
 
 def render_basic_sharded(ctx, frame, params, world_size: int, group=None, merge: str = "reduce"):

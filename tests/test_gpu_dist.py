@@ -85,7 +85,9 @@ def test_slice_kernels_against_numpy(group, loaded):
     keys = (rng.integers(1, 0x7F800000, size=(ns, S), dtype=np.int64) << 32) | rng.integers(0, 2 ** 20, size=(ns, S), dtype=np.int64)
     keys[rng.random((ns, S)) < 0.4] = np.iinfo(np.int64).max
     t = torch.from_numpy(keys.reshape(-1).copy()).to(group)
-    ctx.set_stream(torch.cuda.current_stream(group).cuda_stream)
+    stream = torch.cuda.Stream(group)           # (torch's default stream has the handle 0 = "the context's own stream")
+    stream.wait_stream(torch.cuda.current_stream(group))
+    ctx.set_stream(stream.cuda_stream)
     try:
         ctx.merge_min_slices(t.data_ptr(), ns, S)
         want = keys.min(axis=0)
