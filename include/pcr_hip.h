@@ -172,17 +172,24 @@ int pcr_fence_wait(pcr_ctx *ctx, int slot, void *hip_stream);
  * the same points; the Huffman decode runs every frame in all of them. Only what the layout's kernel reads is kept: the
  * raw cluster-interleaved words of the file, the int32/int8 decoder tables and the cluster prefix are released by the first
  * frame after the last batch was uploaded (pcr_upload_tail has to come before that frame).
- *   PCR_LAYOUT_WORDS          per chain the sequence of 32-bit words it consumes (320 B per chain allocated, ~3 B per
- *                             point read): the decode keeps a five-word queue per lane.
+ *   PCR_LAYOUT_WORDS          per chain the sequence of 32-bit words it consumes, kept compact: per 64 chains only the rows their
+ *                             longest chain consumed (~2.9 B per point resident and read on the benchmark stream: the memory-lean
+ *                             layout, 4.2 B per point with all side data against 3.7 in the file); the decode keeps a five-word queue
+ *                             per lane. Loading it waits for the device once per 128 batches (the compact size is read back).
  *   PCR_LAYOUT_POINT_WINDOWS  (default) per point the 40 bits of its chain's stream that start at the point's first bit
  *                             (5 B per point, a u32 and a u8 plane): no queue in the decode, a point's first table read
  *                             off the dependent chain, fewer instructions per point for ~1.4x the bytes per frame, on a
  *                             kernel bound by issue and latency, not by HBM.
- *   PCR_LAYOUT_BOTH           both resident: either decode variant can draw a frame (pcr_set_render_variant). */
+ *   PCR_LAYOUT_BOTH           both resident: either decode variant can draw a frame (pcr_set_render_variant).
+ *   PCR_LAYOUT_AUTO           POINT_WINDOWS unless the stream's windows would exceed the budget of pcr_set_hbm_budget (bytes; 0 = no
+ *                             budget, the default): then WORDS. pcr_stream_layout tells which one the loaded stream got. */
 #define PCR_LAYOUT_WORDS 0
 #define PCR_LAYOUT_POINT_WINDOWS 1
 #define PCR_LAYOUT_BOTH 2
+#define PCR_LAYOUT_AUTO 3
 int pcr_set_stream_layout(pcr_ctx *ctx, int layout);
+int pcr_set_hbm_budget(pcr_ctx *ctx, int64_t bytes);
+int pcr_stream_layout(const pcr_ctx *ctx);
 /* Which decode variant draws. AUTO (default): the one the stream's layout holds; with PCR_LAYOUT_BOTH the point-window
  * variant while the image has at most 4096 pixels (one LDS framebuffer window) per loaded batch, the packed-words variant
  * beyond that, where the frame is bound by global framebuffer traffic and the smaller stream wins. WORDS / POINT_WINDOWS

@@ -62,10 +62,20 @@ struct pcr_ctx {
     hipEvent_t any_generic_ev = nullptr;
     bool any_generic_pending = false;
     uint32_t *d_packed_table = nullptr;         // k_render's table entries, 4096 per batch (k_transcode)
-    uint32_t *d_lane_words = nullptr;           // lane-major copy of the word stream (k_transcode), LW_ROWS x 1024 per batch
+    uint32_t *d_lane_words = nullptr;           // k_transcode's scratch: lane-major copy of the word stream, LW_ROWS x 1024 per batch of a chunk
+    // PCR_LAYOUT_WORDS / _BOTH: the compact copy k_render's packed-words variant reads (k_pack_words). One device allocation per
+    // transcode chunk, sized from the rows the chunk's waves consumed (read back: loading such a stream synchronises per chunk)
+    bool keep_words = false;
+    std::vector<uint32_t *> lw_segments;
+    const uint32_t **d_lw_block = nullptr;      // [nB] the batch's block inside its chunk's segment
+    uint32_t *d_lw_wave_row = nullptr;          // [nB * (LWC_WAVES + 1)] first row of every wave inside the block, and the end
+    uint32_t *d_wave_rows = nullptr;            // [TRANSCODE_CHUNK * LWC_WAVES] rows per wave of the chunk being transcoded (k_transcode)
+    uint32_t *h_wave_rows = nullptr;            // pinned: the same on the host, then the staging of the two arrays above
+    int64_t provisional_for = -1;               // batches_loaded when the provisional walk of an incomplete stream's last batch was last done
     uint8_t *d_point_windows = nullptr;         // PCR_LAYOUT_POINT_WINDOWS: 40-bit view per point (k_transcode), PW_BATCH_BYTES per batch
     int layout = PCR_LAYOUT_POINT_WINDOWS;      // of the stream being loaded (pcr_set_stream_layout, fixed at pcr_stream_begin)
     int next_layout = PCR_LAYOUT_POINT_WINDOWS;
+    int64_t hbm_budget = 0;                     // PCR_LAYOUT_AUTO: streams whose point windows would take more than this are loaded as packed words
     int variant = PCR_VARIANT_AUTO;             // which k_render variant draws a stream that has both layouts resident
     int64_t transcoded = 0;                     // batches [0, transcoded) of d_lane_words / d_point_windows are final
     // PCR_LAYOUT_POINT_WINDOWS keeps no lane-major words: d_lane_words is then k_transcode's scratch for TRANSCODE_CHUNK
@@ -173,6 +183,8 @@ void free_stream_buffers(pcr_ctx *c)
     c->batches_resident = 0;
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_colors_t); dfree(c->d_lod); dfree(c->d_win);
+    for (uint32_t *seg : c->lw_segments) (void)hipFree(seg);
+    c->lw_segments.clear(); dfree(c->d_lw_block); dfree(c->d_lw_wave_row); dfree(c->d_wave_rows); c->provisional_for = -1;
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); dfree(c->d_batch_runs); c->transcoded = 0;
     dfree(c->d_order); dfree(c->d_chunk_count); dfree(c->d_any_generic); c->order_stride = 0;
 
@@ -234,6 +246,7 @@ StreamView make_stream_view(pcr_ctx *c)
     s.separate = c->d_separate; s.separate_sizes = c->d_sep_sizes; s.table_values = c->d_table_values;
     s.table_lens = c->d_table_lens; s.cluster_sizes = c->d_cluster_sizes; s.colors = c->d_colors; s.colors_t = c->d_colors_t; s.color_block_bytes = c->color_bytes == PCR_COLOR_BYTES_PER_BATCH_BC7 ? 16u : 8u;
     s.lane_words = c->d_lane_words; s.batch_flags = c->d_batch_flags; s.packed_table = c->d_packed_table;
+    s.lw_block = c->d_lw_block; s.lw_wave_row = c->d_lw_wave_row;
     s.point_windows = c->d_point_windows; s.batch_runs = c->d_batch_runs;
     s.encoded_words = c->enc_words; s.separate_words = c->sep_words;
     s.num_batches = c->visible_batches(); s.batch_index_base = c->batch_index_base;
@@ -265,27 +278,62 @@ bool maybe_generic_batches(pcr_ctx *c)
 // final once the batch behind it is loaded (its chains' tail over-reads, SURVEY B.4, reach into those words) or the
 // stream is complete; the last batch of an incomplete stream is walked provisionally (`include_provisional`, render
 // time only) and walked again when more data arrives. Part of loading: pcr_upload_batches calls this for what it can.
-void enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
+int enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
 {
     const int64_t loaded = c->batches_loaded;
     const int64_t final_end = loaded == c->hdr.num_batches ? loaded : loaded - 1;
     const int64_t end = include_provisional ? loaded : final_end;
+    // (the provisional walk of the last batch is the same until more data arrives: once per arrival, not once per frame)
+    if (end > c->transcoded && c->transcoded == final_end && c->provisional_for == loaded) return PCR_OK;
     if (end > c->transcoded) {
         for (int64_t b0 = c->transcoded; b0 < end; ) {
-            const int64_t n = c->lane_words_scratch ? std::min(TRANSCODE_CHUNK, end - b0) : end - b0;
+            const int64_t n = std::min(TRANSCODE_CHUNK, end - b0);
             hipLaunchKernelGGL(k_transcode, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
                                make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows, c->d_colors_t,
-                               c->d_any_generic, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
+                               c->d_any_generic, (int)b0, (int)b0, c->keep_words ? c->d_wave_rows : nullptr);
             hipLaunchKernelGGL(k_bounds, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
-                               make_stream_view(c), c->d_lane_words, c->d_batch_runs, (int)b0, (int)(c->lane_words_scratch ? b0 : 0));
+                               make_stream_view(c), c->d_lane_words, c->d_batch_runs, (int)b0, (int)b0);
+            if (c->keep_words) {
+                // the compact copy: how many rows did every wave of the chunk consume? (the one place loading waits for the device)
+                uint32_t *h = c->h_wave_rows;
+                HIP_TRY(c, hipMemcpyAsync(h, c->d_wave_rows, (size_t)n * LWC_WAVES * 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+                const uint32_t **h_block = reinterpret_cast<const uint32_t **>(h + TRANSCODE_CHUNK * LWC_WAVES);
+                uint32_t *h_rows = h + TRANSCODE_CHUNK * LWC_WAVES + TRANSCODE_CHUNK * 2;
+                std::vector<size_t> first_row((size_t)n);
+                size_t total_rows = 0;
+                for (int64_t i = 0; i < n; ++i) {
+                    first_row[(size_t)i] = total_rows;
+                    uint32_t r = 0;
+                    for (int w = 0; w < LWC_WAVES; ++w) {
+                        h_rows[i * (LWC_WAVES + 1) + w] = r;
+                        r += std::min<uint32_t>(std::max<uint32_t>(h[i * LWC_WAVES + w], 2u), (uint32_t)LW_ROWS);
+                    }
+                    h_rows[i * (LWC_WAVES + 1) + LWC_WAVES] = r;
+                    total_rows += r;
+                }
+                uint32_t *seg = nullptr;
+                if (hipMalloc((void **)&seg, total_rows * LWC_ROW_BYTES) != hipSuccess)
+                    return set_err(c, PCR_E_NOMEM, "out of device memory for %zu bytes of packed words", total_rows * (size_t)LWC_ROW_BYTES);
+                c->lw_segments.push_back(seg);
+                c->stream_bytes += total_rows * LWC_ROW_BYTES;
+                for (int64_t i = 0; i < n; ++i) h_block[i] = seg + first_row[(size_t)i] * 64;
+                HIP_TRY(c, hipMemcpyAsync(c->d_lw_block + b0, h_block, (size_t)n * sizeof(uint32_t *), hipMemcpyHostToDevice, st));
+                HIP_TRY(c, hipMemcpyAsync(c->d_lw_wave_row + b0 * (LWC_WAVES + 1), h_rows, (size_t)n * (LWC_WAVES + 1) * 4, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_pack_words, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st, c->d_lane_words, (uint32_t *const *)c->d_lw_block,
+                                   c->d_lw_wave_row, (int)b0, (int)b0);
+                HIP_TRY(c, hipStreamSynchronize(st));       // (the pinned staging is reused by the next chunk)
+            }
             b0 += n;
         }
         c->transcoded = std::max(c->transcoded, final_end);
+        c->provisional_for = end > final_end ? loaded : -1;
         // the sticky "some batch needs the checked kernel" word follows every transcode to the host
         (void)hipMemcpyAsync(c->h_any_generic, c->d_any_generic, 4, hipMemcpyDeviceToHost, st);
         (void)hipEventRecord(c->any_generic_ev, st);
         c->any_generic_pending = true;
     }
+    return PCR_OK;
 }
 
 // Dynamic LDS of a frame's k_render launches: the small configuration (two workgroups per CU) unless the image has more
@@ -331,7 +379,8 @@ void maybe_finalize(pcr_ctx *c)
     dfree_counted(c, c->d_cluster_sizes, nB * 32);
     dfree_counted(c, c->d_colors, nB * (c->color_bytes ? c->color_bytes : (size_t)PCR_COLOR_BYTES_PER_BATCH));     // k_render reads colors_t
     if (*c->h_any_generic == 0) dfree_counted(c, c->d_table_values, nB * 4096);
-    if (c->lane_words_scratch) dfree_counted(c, c->d_lane_words, (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB) * LW_ROWS * PCR_WORKGROUP_SIZE);
+    dfree_counted(c, c->d_lane_words, (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB) * LW_ROWS * PCR_WORKGROUP_SIZE);
+    if (c->d_wave_rows) dfree_counted(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES);
     c->finalized = true;
 }
 
@@ -343,7 +392,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const int64_t nB = c->visible_batches();         // "don't execute a workgroup until all points inside are loaded"
     c->last_frame_batches = nB;
     if (nB == 0) { c->stats_partials = 0; return PCR_OK; }   // huffman_hqs.h:137
-    if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // normally only the provisional last batch of a stream that is still loading
+    if (!c->async_upload && (rc = enqueue_transcode(c, true, c->stream))) return rc;   // normally only the provisional last batch of a stream that is still loading
     maybe_finalize(c);
     constexpr bool color_pass = MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7;
     const int win_pixel_bytes = color_pass ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES;
@@ -412,7 +461,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r02.v76"; }
+const char *pcr_kernel_version(void) { return "r03.v84"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -466,6 +515,7 @@ void pcr_destroy(pcr_ctx *c)
     }
     if (c->any_generic_ev) (void)hipEventDestroy(c->any_generic_ev);
     if (c->h_any_generic) (void)hipHostFree(c->h_any_generic);
+    if (c->h_wave_rows) (void)hipHostFree(c->h_wave_rows);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (hipEvent_t e : c->loader_events) (void)hipEventDestroy(e);
@@ -511,9 +561,18 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
     c->sep_words = h->separate_bytes / 4 + PCR_SEPARATE_PAD_WORDS;
     int rc;
     size_t *acc = &c->stream_bytes;
-    const bool windows = c->next_layout != PCR_LAYOUT_WORDS, words = c->next_layout != PCR_LAYOUT_POINT_WINDOWS;
-    c->lane_words_scratch = !words;
-    const size_t lw_batches = words ? nB : (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB);
+    int layout = c->next_layout;
+    if (layout == PCR_LAYOUT_AUTO) {
+        // what the stream would take as point windows (5 B per point + side data), against the budget the caller set
+        const int64_t as_windows = (int64_t)nB * (int64_t)(PW_BATCH_BYTES + 4 * 4096 + 12288 + 4096 + PCR_COLOR_BYTES_PER_BATCH) + h->separate_bytes;
+        layout = c->hbm_budget > 0 && as_windows > c->hbm_budget ? PCR_LAYOUT_WORDS : PCR_LAYOUT_POINT_WINDOWS;
+    }
+    const bool windows = layout != PCR_LAYOUT_WORDS, words = layout != PCR_LAYOUT_POINT_WINDOWS;
+    c->lane_words_scratch = true;
+    c->keep_words = words;
+    const size_t lw_batches = (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB);
+    if (words && !c->h_wave_rows)       // rows per wave of a chunk, then the staging of its block pointers and row offsets
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_wave_rows, (size_t)TRANSCODE_CHUNK * (LWC_WAVES + 2 + LWC_WAVES + 1) * 4, hipHostMallocDefault));
     if ((rc = dalloc_zero(c, c->d_batches, nB, acc)) || (rc = dalloc_zero(c, c->d_start, nB * 3072, acc)) ||
         (rc = dalloc_zero(c, c->d_encoded, (size_t)c->enc_words + PCR_GUARD_WORDS, acc)) ||
         (rc = dalloc_zero(c, c->d_separate, (size_t)c->sep_words + PCR_GUARD_WORDS, acc)) ||
@@ -527,12 +586,14 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_batch_runs, nB * RUN_WORDS, acc)) ||
         (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES, acc)) ||
         (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
-        (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc)))) {
+        (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc))) ||
+        (words && ((rc = dalloc_zero(c, c->d_lw_block, nB, acc)) || (rc = dalloc_zero(c, c->d_lw_wave_row, nB * (LWC_WAVES + 1), acc)) ||
+                   (rc = dalloc_zero(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES, acc))))) {
         free_stream_buffers(c);
         return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->layout = c->next_layout;
+    c->layout = layout;
     c->stream_open = true;
     return PCR_OK;
 }
@@ -702,7 +763,7 @@ int pcr_upload_batches(pcr_ctx *c, int64_t first_index, int64_t count, const voi
     c->enc_ptr = enc_ptr; c->sep_ptr = sep_ptr;
     for (const View &v : views) c->h_stream_words.push_back(v.ne + v.ns);
     c->batches_loaded += count; c->points_loaded += count * PCR_POINTS_PER_BATCH;   // HuffmanLasLoader.cpp:294-295
-    enqueue_transcode(c, false, st);    // this context's HBM layout of the stream is part of loading it
+    { int trc = enqueue_transcode(c, false, st); if (trc) return trc; }    // this context's HBM layout of the stream is part of loading it
     HIP_TRY(c, hipGetLastError());
     if (c->async_upload) {
         // a batch becomes drawable with the task that brings the words behind it (its chains' tail over-reads)
@@ -734,8 +795,9 @@ int pcr_upload_tail(pcr_ctx *c, const uint32_t *enc, size_t n_enc, const int32_t
     if (n_sep) HIP_TRY(c, hipMemcpyAsync(c->d_separate + c->sep_ptr, sep, n_sep * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->batches_loaded > 0 && c->transcoded >= c->batches_loaded) c->transcoded = c->batches_loaded - 1;   // its over-reads see these words
+    c->provisional_for = -1;
     if (c->async_upload) {           // no render-time transcode in this mode: redo the last batch now
-        enqueue_transcode(c, true, c->stream);
+        { int trc = enqueue_transcode(c, true, c->stream); if (trc) return trc; }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->batches_resident = c->transcoded;
     }
@@ -754,11 +816,20 @@ int pcr_stream_unload(pcr_ctx *c)
 int pcr_set_stream_layout(pcr_ctx *c, int layout)
 {
     if (!c) return PCR_E_ARG;
-    if (layout != PCR_LAYOUT_WORDS && layout != PCR_LAYOUT_POINT_WINDOWS && layout != PCR_LAYOUT_BOTH)
+    if (layout != PCR_LAYOUT_WORDS && layout != PCR_LAYOUT_POINT_WINDOWS && layout != PCR_LAYOUT_BOTH && layout != PCR_LAYOUT_AUTO)
         return set_err(c, PCR_E_ARG, "unknown stream layout %d", layout);
     c->next_layout = layout;         // the stream that is loaded keeps the layout it was loaded with
     return PCR_OK;
 }
+
+int pcr_set_hbm_budget(pcr_ctx *c, int64_t bytes)
+{
+    if (!c || bytes < 0) return PCR_E_ARG;
+    c->hbm_budget = bytes;
+    return PCR_OK;
+}
+
+int pcr_stream_layout(const pcr_ctx *c) { return c && c->stream_open ? c->layout : -1; }
 
 int pcr_set_render_variant(pcr_ctx *c, int variant)
 {
@@ -889,7 +960,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     if (nB == 0) return pcr_clear(c);
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
-    if (!c->async_upload) enqueue_transcode(c, true, c->stream);   // the prepass sorts batches by what k_transcode found out about them
+    if (!c->async_upload && (rc = enqueue_transcode(c, true, c->stream))) return rc;   // the prepass sorts batches by what k_transcode found out about them
     maybe_finalize(c);
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
@@ -932,7 +1003,7 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
         if ((rc = launch_resolve(c, p_done, false))) return rc;
         return pcr_frame_begin(c, p_next, method);
     }
-    if (!c->async_upload) enqueue_transcode(c, true, c->stream);
+    if (!c->async_upload && (rc = enqueue_transcode(c, true, c->stream))) return rc;
     maybe_finalize(c);
     RenderArgs a = make_args(c, p_next, hqs);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;

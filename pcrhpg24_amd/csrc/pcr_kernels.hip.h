@@ -73,6 +73,11 @@ __device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_byt
 // A chain consumes 2 words up front and one per 32 decoded bits (<= 192 x 12 / 32 = 72), and k_render reads four ahead.
 constexpr int LW_ROWS        = 80;
 constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
+// PCR_LAYOUT_WORDS keeps that copy compact (k_pack_words): per wave (64 chains) only the rows its longest chain consumed, 256
+// bytes each, one block per batch. The benchmark stream's chains take 43.6 words on average, a wave's longest 46.7, against
+// the 80 rows of the transcode's scratch form: 2.9 B per point resident instead of 5.
+constexpr uint32_t LWC_ROW_BYTES = 64 * 4;
+constexpr int LWC_WAVES = PCR_WORKGROUP_SIZE / 64;          // 16 blocks of rows per batch + one entry for the end
 // Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 40 bits of the chain's own
 // bit stream that start at the point's first bit -- its three symbols (<= 36 bits) lie inside. Stored as two planes per
 // batch: PW_ROWS rows of 1024 x u32 (bits 0..31 of the window) followed by PW_ROWS rows of 1024 x u8 (bits 32..39). Row i is
@@ -117,7 +122,9 @@ struct StreamView {
                                       // k_render read the blocks of one segment side by side (as the file has them a wave's 64
                                       // blocks lie 32 B apart and every 128-byte line was fetched once per segment: 4x)
     uint32_t color_block_bytes;       // 8 (BC1) / 16 (BC7)
-    const uint32_t *lane_words;       // [nB*LW_ROWS*1024] lane-major stream written by k_transcode
+    const uint32_t *lane_words;       // k_transcode's scratch: [chunk][LW_ROWS][1024] lane-major stream
+    const uint32_t *const *lw_block;  // [nB] PCR_LAYOUT_WORDS: the batch's compact copy (k_pack_words), or NULL (layout)
+    const uint32_t *lw_wave_row;      // [nB * (LWC_WAVES + 1)] first row of each wave's rows inside the batch's block, and the end
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
     const uint8_t  *point_windows;    // [nB * PW_BATCH_BYTES + PW_GUARD_BYTES] or NULL (layout), written by k_transcode
@@ -571,7 +578,7 @@ __device__ __forceinline__ uint32_t pack_table_entry(int32_t value, uint32_t lby
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, uint32_t *lane_words, uint32_t *batch_flags,
                                                                   uint32_t *packed_table, uint8_t *point_windows, uint8_t *colors_t,
-                                                                  uint32_t *any_generic, int first_batch, int lane_words_first)
+                                                                  uint32_t *any_generic, int first_batch, int lane_words_first, uint32_t *wave_rows)
 {
     const uint32_t b = (uint32_t)first_batch + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -662,6 +669,13 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // rows of the lane-major copy my wave's longest chain wrote (PCR_LAYOUT_WORDS keeps exactly those, k_pack_words)
+    if (wave_rows) {
+        uint32_t rows = row;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) rows = max(rows, (uint32_t)__shfl_xor((int)rows, m));
+        if ((tid & 63u) == 0) wave_rows[(size_t)(b - (uint32_t)lane_words_first) * LWC_WAVES + (tid >> 6)] = rows;
+    }
     // may k_render read this batch's escapes from its LDS pool unchecked? (same pool rule as there)
     const int32_t *ssz = s.separate_sizes + (size_t)b * 1024;
     const uint32_t esc_total = (uint32_t)ssz[1023];
@@ -695,6 +709,18 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
             pwl[(size_t)i * PCR_WORKGROUP_SIZE] = (uint8_t)(lo >> 24);   // bits 32..39
         }
     }
+}
+
+// k_pack_words: the compact copy of the lane-major words (PCR_LAYOUT_WORDS), once per loaded batch behind k_transcode: wave w of
+// batch b copies rows [0, rows_w) of its 64 columns from the scratch form into the batch's block, 256 bytes per row.
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_pack_words(const uint32_t *lane_words, uint32_t *const *lw_block,
+                                                                   const uint32_t *lw_wave_row, int first_batch, int lane_words_first)
+{
+    const uint32_t b = (uint32_t)first_batch + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t *src = lane_words + (size_t)(b - (uint32_t)lane_words_first) * LW_ROWS * PCR_WORKGROUP_SIZE + tid;
+    const uint32_t r0 = lw_wave_row[(size_t)b * (LWC_WAVES + 1) + wave], r1 = lw_wave_row[(size_t)b * (LWC_WAVES + 1) + wave + 1];
+    uint32_t *dst = lw_block[b] + (size_t)r0 * 64 + lane;
+    for (uint32_t r = 0; r < r1 - r0; ++r) dst[(size_t)r * 64] = src[(size_t)r * PCR_WORKGROUP_SIZE];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1019,23 +1045,33 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // (Cur/Next of :416-419 are the first two words; the stand-in w0 = 0 is "fully consumed" from the start.)
     // LAYOUT_POINT_WINDOWS: the view of every point was cut by k_transcode; row i of point_windows is read at point i
     // (requested two points earlier) and there is no queue.
-    const char *lwb = reinterpret_cast<const char *>(a.s.lane_words + (size_t)b * LW_ROWS * PCR_WORKGROUP_SIZE);   // uniform
-    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + byte_off); };
+    // LAYOUT_WORDS: my wave's rows of the batch's compact block (k_pack_words); a request past the last row the wave's longest
+    // chain consumed is clamped to that row (such a word is requested ahead but never looked at)
+    const char *lwb = nullptr;
+    uint32_t lw_last = 0;
+    if (LAYOUT == LAYOUT_WORDS) {
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t *wr = a.s.lw_wave_row + (size_t)b * (LWC_WAVES + 1) + wave;
+        const uint32_t r0 = wr[0], r1 = wr[1];
+        lwb = reinterpret_cast<const char *>(a.s.lw_block[b]) + (size_t)r0 * LWC_ROW_BYTES;                      // uniform per wave
+        lw_last = (r1 - r0 - 1u) * LWC_ROW_BYTES + (tid & 63u) * 4u;
+    }
+    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + min(byte_off, lw_last)); };
     const char *pwb = reinterpret_cast<const char *>(a.s.point_windows) + (size_t)b * PW_BATCH_BYTES;               // uniform
     // the 40-bit window of a point as the top of a 64-bit view: high plane u32, low plane u8 (the 24 bits below are zero)
     // (per-lane byte offsets that advance by a row: with a uniform pointer that advances instead, hipcc adds the lane's
     // offset to it with a 64-bit vector add in front of every load)
     auto pw_load_hi = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pwb + byte_off); };
     auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint8_t *>(pwb + byte_off); };
-    uint32_t lwo = tid * 4;                                 // byte offset of my column in the row of far0 / in the high plane's row
+    uint32_t lwo = LAYOUT == LAYOUT_WORDS ? (tid & 63u) * 4 : tid * 4;     // byte offset of my column in the row of far0 / in the high plane's row
     uint32_t lwo2 = PW_HI_BYTES + tid;                      // ... in the low plane's row
     uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
     uint64_t bits;
     uint32_t nwin_hi = 0, nwin_lo = 0;
     if (LAYOUT == LAYOUT_WORDS) {
-        w1 = lw_load(lwo); w2 = lw_load(lwo + LW_ROW_BYTES);
-        far0 = lw_load(lwo + 2 * LW_ROW_BYTES); far1 = lw_load(lwo + 3 * LW_ROW_BYTES);
-        lwo += 2 * LW_ROW_BYTES;
+        w1 = lw_load(lwo); w2 = lw_load(lwo + LWC_ROW_BYTES);
+        far0 = lw_load(lwo + 2 * LWC_ROW_BYTES); far1 = lw_load(lwo + 3 * LWC_ROW_BYTES);
+        lwo += 2 * LWC_ROW_BYTES;
         bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
     } else {
         bits = ((uint64_t)pw_load_hi(lwo) << 32) | (pw_load_lo(lwo2) << 24);
@@ -1155,11 +1191,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         const uint32_t n1_ = k_ == 2u ? w1 : k_ == 1u ? w2 : far0;                         \
         const uint32_t n2_ = k_ == 2u ? w2 : k_ == 1u ? far0 : far1;                       \
         w0 = n0_; w1 = n1_; w2 = n2_;                                                      \
-        lwo += (2u - k_) * LW_ROW_BYTES;                                                   \
+        lwo += (2u - k_) * LWC_ROW_BYTES;                                                  \
         /* only the words that moved up are fetched: 0.7 loads per point instead of 2 */   \
         if (k_ == 1u) far0 = far1;                                                         \
         if (k_ == 0u) far0 = lw_load(lwo);                                                 \
-        if (k_ != 2u) far1 = lw_load(lwo + LW_ROW_BYTES);                                  \
+        if (k_ != 2u) far1 = lw_load(lwo + LWC_ROW_BYTES);                                 \
         bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare); \
         sft = SFT0;                                                                        \
     } while (0)
@@ -1323,12 +1359,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
         }
 #endif
-#ifdef PCR_EXP_EXTRA_LOAD   /* experiment: 4 (or 8) more bytes of HBM traffic per point, consumed at the end of the point */
-        const uint32_t extra0 = lw_load((uint32_t)i * LW_ROW_BYTES + tid * 4);
-#if PCR_EXP_EXTRA_LOAD > 1
-        const uint32_t extra1 = lw_load((uint32_t)(i + 8) * LW_ROW_BYTES + tid * 4);
-#endif
-#endif
         uint32_t d0, d1, d2;
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {
             // The first symbol's key is the top of the point's own window: its entry was requested a whole point ago (the one of
@@ -1481,12 +1511,6 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
         }
         if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo << 24; }
-#ifdef PCR_EXP_EXTRA_LOAD
-        asm volatile("; extra load consumed %0" :: "v"(extra0));
-#if PCR_EXP_EXTRA_LOAD > 1
-        asm volatile("; extra load consumed %0" :: "v"(extra1));
-#endif
-#endif
       }
     }
     if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, npr_run - 1); flush_run(); }

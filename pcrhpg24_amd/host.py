@@ -446,11 +446,19 @@ class Context:
     def flip_sign(self):
         self._chk(self.lib.pcr_flip_sign(self.h), "pcr_flip_sign")
 
-    LAYOUT_WORDS, LAYOUT_POINT_WINDOWS, LAYOUT_BOTH = 0, 1, 2
+    LAYOUT_WORDS, LAYOUT_POINT_WINDOWS, LAYOUT_BOTH, LAYOUT_AUTO = 0, 1, 2, 3
 
     def set_stream_layout(self, layout: int) -> None:
         """HBM layout of the next stream this context loads (pcr_hip.h: PCR_LAYOUT_*)."""
         self._chk(self.lib.pcr_set_stream_layout(self.h, int(layout)), "pcr_set_stream_layout")
+
+    def set_hbm_budget(self, nbytes: int) -> None:
+        """LAYOUT_AUTO: a stream whose point windows would take more than this many bytes is loaded as packed words."""
+        self._chk(self.lib.pcr_set_hbm_budget(self.h, int(nbytes)), "pcr_set_hbm_budget")
+
+    @property
+    def stream_layout(self) -> int:
+        return int(self.lib.pcr_stream_layout(self.h))
 
     VARIANT_AUTO, VARIANT_WORDS, VARIANT_POINT_WINDOWS = 0, 1, 2
 

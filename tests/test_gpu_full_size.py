@@ -151,3 +151,33 @@ def test_4096x4096_with_culling_matches_the_oracle(big):
                 assert 0.25 * hf.numBatches < ost["batches_culled"] < 0.75 * hf.numBatches, ost
     finally:
         c.close()
+
+
+def test_packed_words_layout_keeps_the_compression(big):
+    """PCR_LAYOUT_WORDS holds per 64 chains only the rows their longest chain consumed -- at most 4.3 B per
+    point resident for the benchmark stream (3.73 in the file), against 6.3 for the point windows -- and PCR_LAYOUT_AUTO picks it
+    when the windows would not fit a budget. Frames are the oracle's either way."""
+    _, hf, of = big
+    p = params()
+    ofb, ost = of.render_basic(p, nthreads=16)
+    c = P.Context(0)
+    try:
+        c.set_image_size(W, H)
+        per_point = {}
+        for name, layout, budget in (("words", P.Context.LAYOUT_WORDS, 0), ("auto, 500 MB budget", P.Context.LAYOUT_AUTO, 500 << 20),
+                                     ("auto, no budget", P.Context.LAYOUT_AUTO, 0)):
+            c.set_hbm_budget(budget)
+            c.set_stream_layout(layout)
+            c.stream_begin(hf.header(), 0)
+            for b0 in range(0, hf.numBatches, 100):
+                c.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, hf.numBatches))])
+            c.frame_begin(p); c.render_basic(p)
+            assert c.stats() == ost and np.array_equal(c.read_framebuffer(full=True), ofb), name
+            per_point[name] = c.resident_bytes / hf.numPoints
+            want = P.Context.LAYOUT_POINT_WINDOWS if name == "auto, no budget" else P.Context.LAYOUT_WORDS
+            assert c.stream_layout == want, name
+            c.stream_unload()
+        assert per_point["words"] <= 4.3 and per_point["auto, 500 MB budget"] == per_point["words"], per_point
+        assert 6.0 < per_point["auto, no budget"] < 6.6, per_point
+    finally:
+        c.close()

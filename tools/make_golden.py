@@ -21,6 +21,9 @@ source text is stored.
                              rgbcx::encode_bc1(level 8) as src/preprocess.cpp:282-297 calls it. Only the (time, lane)
                              interleave of src/preprocess.cpp:552-573 and the record layout of
                              include/BatchDumpData.h:151-202 are restated here (those sources need GL/CUDA headers).
+  ref_packed_bc7.huffman     one batch packed the same way with BC7 mode-6 colour blocks from the reference's bc7enc (HQS method only)
+  ref_packed_lowentropy.huffman   10 000 points padded to one batch by repeating the last point: SURVEY B.4's worst case (one-bit
+                             codes; the reference's tail artefact starts 32-64 symbols before the chain ends)
   ref_packed_batch_expected.json   cameras, SHA-256 of the oracle's framebuffers / sums / resolves for that file, the
                              in-chain positions at which the lockstep decode differs from the reference's own scalar
                              decoder (huffman.h:433-477; must all be SURVEY B.4 tail positions) and the depth-tie counts
@@ -179,35 +182,22 @@ def assemble_huffman_file(records) -> bytes:
     return head + b"".join(blobs)
 
 
-def ref_packed_batch():
-    """Two batches packed by the reference's own huffman.h / mymorton.h / rgbcx (oracle/_ref), see the module docstring."""
+def pack_with_the_reference_library(px, py, pz, col, scale, offset, bc7=False):
+    """points -> (.huffman bytes, records) with every code bit from the reference's own library (oracle/_ref): Morton order
+    (src/mymorton.h), dictionary + table + per-chain packing (include/huffman.h), colour blocks (rgbcx BC1, or bc7enc mode 6
+    as Chain::encode_color_bc7 calls it, src/preprocess.cpp:299-316). Restated: padding (src/preprocess.cpp:945-955), the
+    (time, lane) interleave (:552-573) and the record layout (include/BatchDumpData.h:151-202)."""
     ref = refpin.ref_lib()
-    rng = np.random.default_rng(20241004)
-    # a 36 m x 36 m patch of a heightfield at the benchmark stream's density (0.1 m spacing, LAS scale 0.001): 362^2 points
-    side = 362
-    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="xy")
-    px = (100_000 + gx * 100 + rng.integers(-40, 41, gx.shape)).ravel().astype(np.int32)
-    py = (200_000 + gy * 100 + rng.integers(-40, 41, gy.shape)).ravel().astype(np.int32)
-    pz = (40_000 + 3000 * np.sin(px / 3000.0) * np.cos(py / 4100.0) + 400 * np.sin(px / 170.0 + py / 230.0)).astype(np.int64)
-    pz = (pz + rng.integers(-15, 16, pz.shape)).astype(np.int32)
-    cr = np.clip(128 + 100 * np.sin(px / 5000.0) + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
-    cg = np.clip(128 + 100 * np.cos(py / 7000.0) + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
-    cb = np.clip(90 + (pz - 36_000) // 60 + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
-    col = (cr | (cg << 8) | (cb << 16)).astype(np.uint32)
-    scale, offset = (0.001, 0.001, 0.001), (0.0, 0.0, 0.0)
-    las_min = tuple(float(a.min()) * 0.001 for a in (px, py, pz))
-    las_max = tuple(float(a.max()) * 0.001 for a in (px, py, pz))
-    n_in = len(px)
-    src_points = (px.copy(), py.copy(), pz.copy(), col.copy())
+    las_min = tuple(float(a.min()) * s_ for a, s_ in zip((px, py, pz), scale))
+    las_max = tuple(float(a.max()) * s_ for a, s_ in zip((px, py, pz), scale))
     # src/preprocess.cpp:945-955: pad to a multiple of 65 536 by repeating the last point
-    pad = (-n_in) % 65536
+    pad = (-len(px)) % 65536
     px, py, pz, col = (np.concatenate([a, np.full(pad, a[-1], a.dtype)]) for a in (px, py, pz, col))
     # src/preprocess.cpp:959-977 with the reference's own src/mymorton.h:39-58
     order = np.zeros(len(px), np.uint32)
     ref.ref_morton_order(px.ctypes.data, py.ctypes.data, pz.ctypes.data, len(px), order.ctypes.data)
     px, py, pz, col = px[order], py[order], pz[order], col[order]
-
-    records, scalar_mismatch = [], []
+    records = []
     for b in range(len(px) // 65536):
         sl = slice(b * 65536, (b + 1) * 65536)
         X, Y, Z, Cc = (a[sl].reshape(1024, 64) for a in (px, py, pz, col))
@@ -239,11 +229,16 @@ def ref_packed_batch():
             cluster_sizes.append(len(enc))
         sep = np.concatenate([packed[c][1] for c in range(1024)]) if any(len(packed[c][1]) for c in range(1024)) else np.zeros(0, np.int32)
         sep_sizes = np.cumsum([len(packed[c][1]) for c in range(1024)]).astype(np.int32)
-        # Chain::encode_color_bc1 (:282-297): the reference's rgbcx, 16 points per block, chain-major
-        blocks = np.zeros((4096, 8), np.uint8)
         flat = np.ascontiguousarray(Cc.reshape(4096, 16))
-        for k in range(4096):
-            ref.ref_bc1_encode(flat[k].ctypes.data, blocks[k].ctypes.data)
+        if bc7:       # Chain::encode_color_bc7 (:299-316): bc7enc, mode 6 only, opaque
+            blocks = np.zeros((4096, 16), np.uint8)
+            rgba = np.ascontiguousarray(flat | np.uint32(0xFF000000))
+            for k in range(4096):
+                ref.ref_bc7_encode(rgba[k].ctypes.data, blocks[k].ctypes.data)
+        else:         # Chain::encode_color_bc1 (:282-297): the reference's rgbcx, 16 points per block, chain-major
+            blocks = np.zeros((4096, 8), np.uint8)
+            for k in range(4096):
+                ref.ref_bc1_encode(flat[k].ctypes.data, blocks[k].ctypes.data)
         mins = [int(A.min()) for A in (X, Y, Z)]; maxs = [int(A.max()) for A in (X, Y, Z)]
         f32 = np.float32
         records.append(dict(
@@ -257,17 +252,70 @@ def ref_packed_batch():
             encoding=np.array(enc, np.uint32), separate=sep.astype(np.int32), color=blocks.reshape(-1)))
         records[-1]["_chains"] = chains
         records[-1]["_xyz"] = np.stack([X, Y, Z], 2)
-    data = assemble_huffman_file(records)
-    open(os.path.join(G, "ref_packed_batch.huffman"), "wb").write(data)
+    return assemble_huffman_file(records), records, (las_min, las_max), len(px)
 
-    # what the lockstep (kernel-order) decode makes of it, against the source points and the reference's scalar decoder
-    of = oracle.OracleFile(data)
+
+def surface_patch(rng, side, spacing=100):
+    """A side x side patch of a heightfield at the benchmark stream's density (0.1 m spacing for 100, LAS scale 0.001)."""
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="xy")
+    px = (100_000 + gx * spacing + rng.integers(-40, 41, gx.shape)).ravel().astype(np.int32)
+    py = (200_000 + gy * spacing + rng.integers(-40, 41, gy.shape)).ravel().astype(np.int32)
+    pz = (40_000 + 3000 * np.sin(px / 3000.0) * np.cos(py / 4100.0) + 400 * np.sin(px / 170.0 + py / 230.0)).astype(np.int64)
+    pz = (pz + rng.integers(-15, 16, pz.shape)).astype(np.int32)
+    cr = np.clip(128 + 100 * np.sin(px / 5000.0) + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
+    cg = np.clip(128 + 100 * np.cos(py / 7000.0) + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
+    cb = np.clip(90 + (pz - 36_000) // 60 + rng.integers(-6, 7, px.shape), 0, 255).astype(np.uint32)
+    return px, py, pz, (cr | (cg << 8) | (cb << 16)).astype(np.uint32)
+
+
+def expected_frames(of, cams, W, H, basic=True):
+    """Oracle frames of a fixture for its cameras x {LOD 100 no cull, LOD 10 cull}: SHA-256 of every buffer."""
+    cases = []
+    for name, p in cams.items():
+        for lod, cull in ((100, 0), (10, 1)):
+            p.lod_percent = lod; p.enable_frustum_culling = cull
+            case = {"camera": name, "lod_percent": lod,
+                    "params": {"transform": list(p.transform), "world_view": list(p.world_view), "proj": list(p.proj),
+                               "enable_frustum_culling": p.enable_frustum_culling}}
+            if basic:
+                fb, s1 = of.render_basic(p)
+                ties = of.count_depth_ties(p, fb)
+                case.update({"stats_basic": s1, "covered_pixels": int((fb[:W * H] != 0xFFFFFFFFFFFFFFFF).sum()),
+                             "depth_tie_pixels": ties[0], "depth_tie_pixels_other_colour": ties[1],
+                             "fb_basic_sha256": sha(fb), "rgba_basic_sha256": sha(oracle.resolve_basic(p, fb))})
+            hfb, s2 = of.render_hqs_depth(p)
+            rg, ba, _ = of.render_hqs_color(p, hfb)
+            case.update({"stats_hqs": s2, "fb_hqs_sha256": sha(hfb), "rg_sha256": sha(rg), "ba_sha256": sha(ba),
+                         "rgba_hqs_sha256": sha(oracle.resolve_hqs(p, hfb, rg, ba))})
+            if not basic:
+                case["covered_pixels"] = int(((hfb[:W * H] >> np.uint64(32)) != 0xFFFFFFFF).sum())
+            cases.append(case)
+    return cases
+
+
+def lockstep_vs_source(of, records):
     tail_positions, wrong_points = [], 0
     for b, r in enumerate(records):
         dec = of.decode_batch(b)                                    # (1024, 64, 3) absolute coordinates
         bad = np.argwhere((dec != r["_xyz"]).any(axis=2))
         wrong_points += len(bad)
         tail_positions += [int(i) for _, i in bad]
+    return {"wrong_points": wrong_points, "min_in_chain_position": min(tail_positions) if tail_positions else None,
+            "positions_histogram": {str(k): int(v) for k, v in zip(*np.unique(tail_positions, return_counts=True))}}
+
+
+def ref_packed_batch():
+    """Two batches packed by the reference's own huffman.h / mymorton.h / rgbcx (oracle/_ref), see the module docstring."""
+    rng = np.random.default_rng(20241004)
+    px, py, pz, col = surface_patch(rng, 362)                       # a 36 m x 36 m patch: 362^2 points
+    scale, offset = (0.001, 0.001, 0.001), (0.0, 0.0, 0.0)
+    n_in = len(px)
+    src_points = (px.copy(), py.copy(), pz.copy(), col.copy())
+    data, records, (las_min, las_max), n_padded = pack_with_the_reference_library(px, py, pz, col, scale, offset)
+    open(os.path.join(G, "ref_packed_batch.huffman"), "wb").write(data)
+
+    # what the lockstep (kernel-order) decode makes of it, against the source points and the reference's scalar decoder
+    of = oracle.OracleFile(data)
     # this repository's own encoder on the same points: everything but the colour blocks (and the symbols parked in escape
     # table slots, which no decoder reads) should be what the reference's library produced
     las = P.LasInfo()
@@ -286,48 +334,83 @@ def ref_packed_batch():
         "far": P.camera_orbit(2.2, -0.8, 420.0, (18.0, 18.0, 3.0), W, H),          # small on screen: the LOD percentage decides
     }
     out = {"stream_sha256": hashlib.sha256(data).hexdigest(), "width": W, "height": H,
-           "source_points": n_in, "padded_points": len(px), "batches": len(records),
-           "encoded_bits_per_point": round(32.0 * sum(len(r["encoding"]) for r in records) / len(px), 3),
+           "source_points": n_in, "padded_points": n_padded, "batches": len(records),
+           "encoded_bits_per_point": round(32.0 * sum(len(r["encoding"]) for r in records) / n_padded, 3),
            "escape_words": int(sum(len(r["separate"]) for r in records)),
            "own_encoder_on_same_points": same,
-           "lockstep_vs_source": {"wrong_points": wrong_points, "min_in_chain_position": min(tail_positions) if tail_positions else None,
-                                  "positions_histogram": {str(k): int(v) for k, v in zip(*np.unique(tail_positions, return_counts=True))}},
-           "cases": []}
-    for name, p in cams.items():
-        for lod, cull in ((100, 0), (10, 1)):
-            p.lod_percent = lod; p.enable_frustum_culling = cull
-            fb, s1 = of.render_basic(p)
-            ties = of.count_depth_ties(p, fb)
-            rgba = oracle.resolve_basic(p, fb)
-            hfb, s2 = of.render_hqs_depth(p)
-            rg, ba, _ = of.render_hqs_color(p, hfb)
-            hrgba = oracle.resolve_hqs(p, hfb, rg, ba)
-            out["cases"].append({
-                "camera": name, "lod_percent": lod,
-                "params": {"transform": list(p.transform), "world_view": list(p.world_view), "proj": list(p.proj),
-                           "enable_frustum_culling": p.enable_frustum_culling},
-                "stats_basic": s1, "stats_hqs": s2,
-                "covered_pixels": int((fb[:W * H] != 0xFFFFFFFFFFFFFFFF).sum()),
-                "depth_tie_pixels": ties[0], "depth_tie_pixels_other_colour": ties[1],
-                "fb_basic_sha256": sha(fb), "rgba_basic_sha256": sha(rgba),
-                "fb_hqs_sha256": sha(hfb), "rg_sha256": sha(rg), "ba_sha256": sha(ba), "rgba_hqs_sha256": sha(hrgba),
-            })
+           "lockstep_vs_source": lockstep_vs_source(of, records),
+           "cases": expected_frames(of, cams, W, H)}
     json.dump(out, open(os.path.join(G, "ref_packed_batch_expected.json"), "w"), indent=1)
     print("ref_packed_batch:", len(data), "bytes;", out["encoded_bits_per_point"], "bit/pt;", out["escape_words"], "escape words;",
-          "lockstep-vs-source wrong points", wrong_points, "min pos", out["lockstep_vs_source"]["min_in_chain_position"],
+          "lockstep-vs-source", out["lockstep_vs_source"]["wrong_points"], "min pos", out["lockstep_vs_source"]["min_in_chain_position"],
           "; own encoder", same, "; covered", [c["covered_pixels"] for c in out["cases"]], "ties", [(c["depth_tie_pixels"], c["depth_tie_pixels_other_colour"]) for c in out["cases"]])
 
+
+def ref_packed_bc7():
+    """One batch with BC7 mode-6 colour blocks from the reference's bc7enc (a file of a reference built with COLOR_COMPRESSION == 7,
+    include/BatchDumpData.h:130-136): drawn by the HQS method only (huffman_hqs/render.cu:297-303)."""
+    rng = np.random.default_rng(20241005)
+    px, py, pz, col = surface_patch(rng, 256)                       # 65 536 points exactly: no padding
+    scale, offset = (0.001, 0.001, 0.001), (0.0, 0.0, 0.0)
+    data, records, _, n_padded = pack_with_the_reference_library(px, py, pz, col, scale, offset, bc7=True)
+    open(os.path.join(G, "ref_packed_bc7.huffman"), "wb").write(data)
+    of = oracle.OracleFile(data)
+    assert of.s.color_format == 7
+    W = H = 384
+    cams = {"patch": P.camera_orbit(-0.4, -0.6, 42.0, (12.8, 12.8, 3.0), W, H),
+            "near": P.camera_orbit(0.9, -0.35, 10.0, (8.0, 18.0, 3.0), W, H)}
+    out = {"stream_sha256": hashlib.sha256(data).hexdigest(), "width": W, "height": H, "source_points": len(px), "padded_points": n_padded,
+           "batches": len(records), "color_format": 7,
+           "encoded_bits_per_point": round(32.0 * sum(len(r["encoding"]) for r in records) / n_padded, 3),
+           "escape_words": int(sum(len(r["separate"]) for r in records)),
+           "lockstep_vs_source": lockstep_vs_source(of, records),
+           "cases": expected_frames(of, cams, W, H, basic=False)}
+    json.dump(out, open(os.path.join(G, "ref_packed_bc7_expected.json"), "w"), indent=1)
+    print("ref_packed_bc7:", len(data), "bytes;", out["encoded_bits_per_point"], "bit/pt; lockstep-vs-source", out["lockstep_vs_source"]["wrong_points"],
+          "covered", [c["covered_pixels"] for c in out["cases"]])
+
+
+def ref_packed_lowentropy():
+    """SURVEY B.4's worst case: 10 000 real points padded to one 65 536-point batch by repeating the last point
+    (src/preprocess.cpp:945-955). Five sixths of the chains are runs of identical points -- one-bit codes -- so the reference's
+    tail over-reads and the de-synchronisation they cause start 32-64 symbols before the end of a chain instead of in its last
+    one or two: the lockstep decode differs from the source in hundreds of points, and the frames below are what the
+    reference's kernels would draw of them (garbage tails included)."""
+    rng = np.random.default_rng(20241006)
+    px, py, pz, col = surface_patch(rng, 100)                       # 10 000 points
+    scale, offset = (0.001, 0.001, 0.001), (0.0, 0.0, 0.0)
+    data, records, _, n_padded = pack_with_the_reference_library(px, py, pz, col, scale, offset)
+    open(os.path.join(G, "ref_packed_lowentropy.huffman"), "wb").write(data)
+    of = oracle.OracleFile(data)
+    W = H = 384
+    cams = {"patch": P.camera_orbit(-0.4, -0.6, 18.0, (5.0, 5.0, 3.0), W, H),
+            "wide": P.camera_orbit(0.7, -0.5, 90.0, (5.0, 5.0, 3.0), W, H)}      # wide enough to see where the garbage tails land
+    out = {"stream_sha256": hashlib.sha256(data).hexdigest(), "width": W, "height": H, "source_points": len(px), "padded_points": n_padded,
+           "batches": len(records),
+           "encoded_bits_per_point": round(32.0 * sum(len(r["encoding"]) for r in records) / n_padded, 3),
+           "escape_words": int(sum(len(r["separate"]) for r in records)),
+           "lockstep_vs_source": lockstep_vs_source(of, records),
+           "cases": expected_frames(of, cams, W, H)}
+    json.dump(out, open(os.path.join(G, "ref_packed_lowentropy_expected.json"), "w"), indent=1)
+    print("ref_packed_lowentropy:", len(data), "bytes;", out["encoded_bits_per_point"], "bit/pt; lockstep-vs-source", out["lockstep_vs_source"],
+          "covered", [c["covered_pixels"] for c in out["cases"]])
+
+
+FIXTURES = {"config1": config1, "bc1_ref": bc1_ref, "bc7_ref": bc7_ref, "huffman_ref": huffman_ref, "ref_packed_batch": ref_packed_batch,
+            "ref_packed_bc7": ref_packed_bc7, "ref_packed_lowentropy": ref_packed_lowentropy}
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # only the named fixtures: python tools/make_golden.py bc7_ref ...
         for name in sys.argv[1:]:
-            {"config1": config1, "bc1_ref": bc1_ref, "bc7_ref": bc7_ref, "huffman_ref": huffman_ref, "ref_packed_batch": ref_packed_batch}[name]()
+            FIXTURES[name]()
         sys.exit(0)
-    config1()
+    # (config1.* is this repository's own encoder's output: it is versioned, not regenerated silently -- name it to rewrite it)
     if os.path.exists(oracle.REF_LIB):
         bc1_ref()
         bc7_ref()
         huffman_ref()
         ref_packed_batch()
+        ref_packed_bc7()
+        ref_packed_lowentropy()
     else:
         print("oracle/_ref/libpcr_ref.so missing: reference-derived fixtures not regenerated")
