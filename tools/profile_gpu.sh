@@ -6,8 +6,8 @@ TAG=${1:-r01}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="$PWD/bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline --no-variants $*"
-BENCH_FULL="$PWD/bench.py --no-cpu-baseline --no-variants $*"
+BENCH="$PWD/bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline --no-variants --no-secondary $*"
+BENCH_FULL="$PWD/bench.py --no-cpu-baseline --no-variants --no-secondary $*"
 cd /tmp
 # the stats pass runs the bench at its default length so that its k_render average can be set beside roofline.kernel_ms
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $BENCH_FULL > "$OUT/stats.log" 2>&1 || { tail -20 "$OUT/stats.log"; exit 1; }
