@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORD = os.path.join(ROOT, "profiles", "r02_bench_basic.json")
+RECORD = os.path.join(ROOT, "profiles", "r03_bench_basic.json")
 
 
 @pytest.fixture(scope="module")
@@ -77,7 +77,7 @@ def test_both_variants_and_the_step_distribution_are_reported(line):
 
 def test_short_and_long_runs_agree():
     """with the clock pre-roll a 20-step run reports what the 200-step run reports (within 3 %)."""
-    with open(os.path.join(ROOT, "profiles", "r02_bench_basic20.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_basic20.json")) as f:
         short = json.loads(f.read().strip().splitlines()[-1])
     with open(RECORD) as f:
         long_ = json.loads(f.read().strip().splitlines()[-1])
