@@ -131,6 +131,21 @@ struct pcr_ctx {
     uint64_t *fb = nullptr, *rg = nullptr, *ba = nullptr;
     uint32_t *d_rgba = nullptr;
     bool accum_dirty = true;    // RG/BA hold something other than zeros (only the HQS colour pass writes them)
+    // dirty tiles (FrameView::tiles): two arrays of one byte per 64 x 16 pixels; `tile_cur` is the one the frame being drawn marks,
+    // the other says where the image may hold something. `tiles_tracked`: every framebuffer write since the last clear went
+    // through a marking kernel (false after merges, external buffers, the 10-10-10 method: the next turn does the whole frame)
+    uint8_t *d_tiles = nullptr;                 // three arrays of ntiles bytes, then three "everything" words
+    uint32_t tiles_x = 0, ntiles = 0, tiles_stride = 0;
+    int tile_cur = 0, tile_prev = 1, tile_spare = 2;    // roles of the three arrays: marked by the frame being drawn / image state / all zero
+    uint32_t tile_e_cur = 1, tile_e_prev = 0, tile_epochs = 1;      // epoch that means "everything" in the cur / prev array's word
+    bool tiles_tracked = false;
+#ifdef PCR_EXP_NO_TILES     /* experiment: the whole frame is resolved and cleared, nothing marks tiles */
+    bool tiles_usable() const { return false; }
+#else
+    bool tiles_usable() const { return d_tiles && fb == own_fb && rg == own_rg && ba == own_ba; }
+#endif
+    uint8_t *tiles_half(int which) const { return d_tiles + (size_t)which * tiles_stride; }
+    uint32_t *tiles_all(int which) const { return reinterpret_cast<uint32_t *>(d_tiles + 3 * (size_t)tiles_stride) + which; }
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // per-launch timing of the dominant kernel (pcr_kernel_timing_*): event pairs around k_render / k_las_render only
@@ -206,7 +221,8 @@ void free_las_buffers(pcr_ctx *c)
 
 void free_frame_buffers(pcr_ctx *c)
 {
-    dfree(c->own_fb); dfree(c->own_rg); dfree(c->own_ba); dfree(c->d_rgba);
+    dfree(c->own_fb); dfree(c->own_rg); dfree(c->own_ba); dfree(c->d_rgba); dfree(c->d_tiles);
+    c->tiles_tracked = false; c->ntiles = c->tiles_x = 0;
     c->fb = c->rg = c->ba = nullptr; c->fb_elems = 0; c->fb_alloc = 0; c->width = c->height = 0;
 }
 
@@ -259,6 +275,9 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.p = *p;
     a.s = make_stream_view(c);
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
+    a.f.tiles = c->tiles_usable() && c->tiles_tracked ? c->tiles_half(c->tile_cur) : nullptr;
+    a.f.tiles_all = c->d_tiles ? c->tiles_all(c->tile_cur) : nullptr;
+    a.f.tiles_x = c->tiles_x; a.f.tiles_epoch = c->tile_e_cur;
     a.lod = c->d_lod; a.win = c->d_win; a.win_hqs = nullptr; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
     a.order = c->d_order;
     a.chunk_count = c->d_chunk_count;
@@ -461,7 +480,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r03.v84"; }
+const char *pcr_kernel_version(void) { return "r03.v88"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -928,9 +947,36 @@ int pcr_set_image_size(pcr_ctx *c, int w, int h)
     HIP_TRY(c, hipMemsetAsync(c->own_rg + c->fb_elems, 0, PCR_FRAME_PAD_ELEMS * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->own_ba + c->fb_elems, 0, PCR_FRAME_PAD_ELEMS * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_rgba, 0, c->fb_alloc * 4, c->stream));
+    c->tiles_x = (((uint32_t)w - 1u) >> TILE_W_SHIFT) + 1u;
+    c->ntiles = c->tiles_x * ((((uint32_t)h + 1u) >> TILE_H_SHIFT) + 1u);        // rows 0 .. h + 1: pixel ids reach w * (h + 1)
+    c->tiles_stride = (c->ntiles + 15u) & ~15u;
+    HIP_TRY(c, hipMalloc((void **)&c->d_tiles, 3 * (size_t)c->tiles_stride + 16));
+    HIP_TRY(c, hipMemsetAsync(c->d_tiles, 0, 3 * (size_t)c->tiles_stride + 16, c->stream));
+    c->tile_cur = 0; c->tile_prev = 1; c->tile_spare = 2; c->tile_e_cur = 1; c->tile_e_prev = 0; c->tile_epochs = 1; c->tiles_tracked = false;
     c->fb = c->own_fb; c->rg = c->own_rg; c->ba = c->own_ba;
     c->accum_dirty = true;
     return pcr_clear(c);
+}
+
+// Tile flags as a clearing kernel has to leave them (clear_tile_flags); afterwards the context keeps track again. The array that was
+// being marked is folded into the image-state array and zeroed by that kernel -- and retired to "spare": the frame that follows marks
+// the all-zero third array, so a prepass running in the SAME launch as the clear (pcr_frame_begin, pcr_frame_turn) does not race with
+// the zeroing. Call before make_args.
+static TileFlags tiles_at_clear(pcr_ctx *c)
+{
+    TileFlags t = { nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0 };
+    if (c->tiles_usable()) {
+        t.cur = c->tiles_half(c->tile_cur); t.prev = c->tiles_half(c->tile_prev); t.cur_all = c->tiles_all(c->tile_cur); t.prev_all = c->tiles_all(c->tile_prev);
+        t.ntiles = c->ntiles; t.tracked = c->tiles_tracked ? 1 : 0;
+        if (c->tile_e_prev == 0) c->tile_e_prev = ++c->tile_epochs;     // (never used yet: any value no word holds)
+        t.e_cur = c->tile_e_cur; t.e_prev = c->tile_e_prev;
+        std::swap(c->tile_cur, c->tile_spare);
+        c->tile_e_cur = ++c->tile_epochs;       // (a fresh epoch: the new array's "everything" word cannot hold it yet)
+        c->tiles_tracked = true;
+    } else {
+        c->tiles_tracked = false;
+    }
+    return t;
 }
 
 int pcr_clear(pcr_ctx *c)
@@ -943,7 +989,7 @@ int pcr_clear(pcr_ctx *c)
     // after a colour pass (or when the buffers changed hands), which saves two 16.6 MB fills per basic frame at 1080p
     uint64_t *rg = c->accum_dirty ? c->rg : nullptr, *ba = c->accum_dirty ? c->ba : nullptr;
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
-    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, c->stream, c->fb, rg, ba, c->fb_elems, c->empty_key);
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, c->stream, c->fb, rg, ba, c->fb_elems, c->empty_key, tiles_at_clear(c));
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     return PCR_OK;
@@ -962,13 +1008,14 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     if (((uintptr_t)c->fb | (uintptr_t)rg | (uintptr_t)ba) & 15) return set_err(c, PCR_E_ARG, "framebuffers must be 16-byte aligned");
     if (!c->async_upload && (rc = enqueue_transcode(c, true, c->stream))) return rc;   // the prepass sorts batches by what k_transcode found out about them
     maybe_finalize(c);
+    const TileFlags tflags = tiles_at_clear(c);
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
     if (method == PCR_METHOD_HQS) a.win_hqs = c->d_win + c->hdr.num_batches;     // ... and the colour pass's plan with it
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
-                       (uint32_t)c->stats_partials, c->fb, rg, ba, c->fb_elems, c->empty_key);
+                       (uint32_t)c->stats_partials, c->fb, rg, ba, c->fb_elems, c->empty_key, tflags);
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     c->prepass_ready = true;
@@ -1010,12 +1057,34 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
     if (hqs) a.win_hqs = c->d_win + c->hdr.num_batches;
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
-    const unsigned grid = (unsigned)c->stats_partials + 2048u;
     const uint32_t pixels = (uint32_t)((size_t)c->width * c->height);
-    if (hqs) hipLaunchKernelGGL(k_frame_turn<true>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
-                                p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key);
-    else     hipLaunchKernelGGL(k_frame_turn<false>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
-                                p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key);
+    if (c->tiles_usable() && c->tiles_tracked) {
+        // only the tiles something was written in (and those the image still holds something in): FrameView::tiles
+        // what the finished frame marked (cur) and what the image may still hold (prev) are read, prev is left zeroed; this launch's
+        // own prepass marks the NEXT frame's tiles in the third array (all zero since the turn before)
+        TileFlags tf = { c->tiles_half(c->tile_cur), c->tiles_half(c->tile_prev), c->tiles_all(c->tile_cur), c->tiles_all(c->tile_prev),
+                         c->ntiles, c->tile_e_cur, c->tile_e_prev, 1 };
+        const int cur = c->tile_cur, prev = c->tile_prev, spare = c->tile_spare;
+        c->tile_cur = spare; c->tile_prev = cur; c->tile_spare = prev;
+        c->tile_e_prev = c->tile_e_cur; c->tile_e_cur = ++c->tile_epochs;
+        a.f.tiles = c->tiles_half(c->tile_cur); a.f.tiles_all = c->tiles_all(c->tile_cur); a.f.tiles_epoch = c->tile_e_cur;      // (the prepass of the next frame)
+        const unsigned grid = (unsigned)c->stats_partials + std::min<unsigned>(c->ntiles, 4096u);
+        if (hqs) hipLaunchKernelGGL(k_frame_turn_tiles<true>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+                                    p_done->colorize_chunks, (uint32_t)c->width, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key,
+                                    tf, c->tiles_x);
+        else     hipLaunchKernelGGL(k_frame_turn_tiles<false>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+                                    p_done->colorize_chunks, (uint32_t)c->width, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key,
+                                    tf, c->tiles_x);
+    } else {
+        const unsigned grid = (unsigned)c->stats_partials + 2048u;
+        const TileFlags tflags = tiles_at_clear(c);
+        a.f.tiles = c->tiles_tracked ? c->tiles_half(c->tile_cur) : nullptr;     // (the prepass of the next frame marks the fresh array)
+        a.f.tiles_all = c->d_tiles ? c->tiles_all(c->tile_cur) : nullptr; a.f.tiles_epoch = c->tile_e_cur;
+        if (hqs) hipLaunchKernelGGL(k_frame_turn<true>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+                                    p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key, tflags);
+        else     hipLaunchKernelGGL(k_frame_turn<false>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+                                    p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key, tflags);
+    }
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     c->prepass_ready = true;
@@ -1133,6 +1202,8 @@ int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
     a.p = *p;
     a.s.batches = c->d_xyzb; a.s.xyz12 = c->d_xyz12; a.s.xyz8 = c->d_xyz8; a.s.xyz4 = c->d_xyz4; a.s.num_batches = nB;
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
+    a.f.tiles = nullptr; a.f.tiles_all = nullptr; a.f.tiles_x = 0; a.f.tiles_epoch = 0;
+    c->tiles_tracked = false;        // (this method's kernels do not mark tiles)
     a.level = c->d_las_level; a.win = c->d_las_win; a.stats = c->d_stats; a.win_capacity = WIN_PIXELS;
     c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
     hipLaunchKernelGGL(k_las_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
@@ -1242,9 +1313,10 @@ size_t pcr_framebuffer_capacity(const pcr_ctx *c)
     return (c->fb == c->own_fb && c->rg == c->own_rg && c->ba == c->own_ba) ? c->fb_alloc : c->fb_elems;
 }
 void *pcr_device_rgba(pcr_ctx *c) { return c ? c->d_rgba : nullptr; }
-void *pcr_device_framebuffer(pcr_ctx *c) { return c ? c->fb : nullptr; }
-void *pcr_device_rg(pcr_ctx *c) { return c ? c->rg : nullptr; }
-void *pcr_device_ba(pcr_ctx *c) { return c ? c->ba : nullptr; }
+// (whoever asks for these may write through them -- a collective merging partial frames in place: no tile flags until the next clear)
+void *pcr_device_framebuffer(pcr_ctx *c) { if (c) c->tiles_tracked = false; return c ? c->fb : nullptr; }
+void *pcr_device_rg(pcr_ctx *c) { if (c) c->tiles_tracked = false; return c ? c->rg : nullptr; }
+void *pcr_device_ba(pcr_ctx *c) { if (c) c->tiles_tracked = false; return c ? c->ba : nullptr; }
 
 int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
 {
@@ -1257,6 +1329,7 @@ int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
     c->fb = fb ? (uint64_t *)fb : c->own_fb;
     c->rg = nrg;
     c->ba = nba;
+    c->tiles_tracked = false;
     return PCR_OK;
 }
 
@@ -1314,6 +1387,7 @@ int pcr_fence_wait(pcr_ctx *c, int slot, void *hip_stream)
 int pcr_merge_min(pcr_ctx *c, const void *other)
 {
     if (!c || !other) return PCR_E_ARG;
+    c->tiles_tracked = false;
     if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
     hipLaunchKernelGGL(k_merge_min, dim3(2048), dim3(256), 0, c->stream, c->fb, (const uint64_t *)other, (uint32_t)c->fb_elems);
     HIP_TRY(c, hipGetLastError());
@@ -1323,6 +1397,7 @@ int pcr_merge_min(pcr_ctx *c, const void *other)
 int pcr_merge_sum(pcr_ctx *c, const void *org, const void *oba)
 {
     if (!c) return PCR_E_ARG;
+    c->tiles_tracked = false;
     if (!c->rg || !c->ba) return set_err(c, PCR_E_ARG, "no accumulation buffers");
     c->accum_dirty = true;
     if (org) hipLaunchKernelGGL(k_merge_sum, dim3(2048), dim3(256), 0, c->stream, c->rg, (const uint64_t *)org, (uint32_t)c->fb_elems);
@@ -1334,6 +1409,7 @@ int pcr_merge_sum(pcr_ctx *c, const void *org, const void *oba)
 int pcr_flip_sign(pcr_ctx *c)
 {
     if (!c) return PCR_E_ARG;
+    c->tiles_tracked = false;
     if (!c->fb) return set_err(c, PCR_E_ARG, "no framebuffer");
     hipLaunchKernelGGL(k_flip_sign, dim3(2048), dim3(256), 0, c->stream, c->fb, (uint32_t)c->fb_elems);
     HIP_TRY(c, hipGetLastError());

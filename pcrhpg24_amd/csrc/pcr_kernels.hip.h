@@ -142,7 +142,20 @@ struct FrameView {
     uint64_t *rg;
     uint64_t *ba;
     uint32_t  fb_elems;
+    // Dirty tiles: one byte per TILE_W x TILE_H pixels of the framebuffer, set for every tile a framebuffer word may be written
+    // in: the prepass marks the tiles under the screen rectangle of every drawn batch's bounding box (every point of the batch
+    // lands inside, in a window or not; a batch without such a rectangle -- its box reaches behind the camera -- sets the word
+    // "everything" instead); a point that lands OUTSIDE that rectangle all the same -- the garbage tail of a chain, SURVEY B.4: a
+    // thousandth of the points, anywhere on the screen -- has its tile marked by k_render, in its off-window branch.
+    // The end of the frame (k_frame_turn_tiles) resolves and clears the marked tiles only -- at 4096x4096 the fused resolve + clear
+    // is 57 us of a 420 us frame streaming 335 MB whether a pixel was touched or not. NULL: nobody keeps track (external buffers,
+    // the 10-10-10 method), the whole frame is resolved and cleared. (Marking EVERY off-window point's tile in k_render's
+    // point loop, with a load in front of the store, cost the loop 6 % for code it practically never runs; profiles/r03_experiments.md.)
+    uint8_t  *tiles;                  // [ntiles]
+    uint32_t *tiles_all;              // "everything": holds tiles_epoch if so (an epoch per frame: the word never has to be zeroed)
+    uint32_t  tiles_x, tiles_epoch;
 };
+constexpr uint32_t TILE_W_SHIFT = 6, TILE_H_SHIFT = 4;     // 64 x 16 pixels: a tile row is 512 contiguous bytes of the framebuffer
 
 // A batch's points are 65 536 consecutive points of the Morton order, chain t = points 64 t .. 64 t + 63. Where the curve
 // jumps, the batch is two (or more) compact clusters far apart: at 1080p 25 of the benchmark's 1526 batches have bounding
@@ -159,6 +172,8 @@ struct WinPlan {
     uint32_t xy[RUNS], wh[RUNS];      // {x0 | y0<<16}, {w | h<<16}; w == 0: none
     uint32_t first[RUNS - 1];
     uint32_t reserved;
+    uint32_t whole_xy, whole_wh;      // the screen rectangle of the batch's own bounding box, in which the prepass marked the dirty tiles
+                                      // (FrameView::tiles); w == 0: it has none, or no tiles are kept
 };
 
 struct RenderArgs {
@@ -405,6 +420,25 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
     assign_windows(window_capacity(esc_total, a.win_pixel_bytes, a.dyn_lds_bytes), mine, whole, runs, r, a.win + b);
     if (a.win_hqs)                                              // (uniform) the colour pass of the same frame: 20-byte pixels
         assign_windows(window_capacity(esc_total, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes), mine, whole, runs, r, a.win_hqs + b);
+    // dirty tiles (FrameView::tiles): everything under the batch's rectangle; a batch without one can write anywhere
+    uint32_t wxy = 0, wwh = 0;
+    if (a.f.tiles) {
+        if (rect_area(whole) > 0) {
+            rect_pack(whole, wxy, wwh);
+            const uint32_t tx0 = (uint32_t)whole.x0 >> TILE_W_SHIFT, ty0 = (uint32_t)whole.y0 >> TILE_H_SHIFT;
+            const uint32_t ntx = ((uint32_t)whole.x1 >> TILE_W_SHIFT) - tx0 + 1u, nty = ((uint32_t)whole.y1 >> TILE_H_SHIFT) - ty0 + 1u;
+            for (uint32_t t = (uint32_t)r; t < ntx * nty; t += RUNS) {
+                const uint32_t ty = t / ntx, tx = t - ty * ntx;
+                a.f.tiles[(ty0 + ty) * a.f.tiles_x + tx0 + tx] = 1;
+            }
+        } else if (r == 0) {
+            *a.f.tiles_all = a.f.tiles_epoch;
+        }
+    }
+    if (r == 0) {
+        a.win[b].whole_xy = wxy; a.win[b].whole_wh = wwh;
+        if (a.win_hqs) { a.win_hqs[b].whole_xy = wxy; a.win_hqs[b].whole_wh = wwh; }
+    }
 }
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
@@ -931,6 +965,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // (the lambdas below capture these scalars, not the argument block: with `a` captured by reference and the loop body
     // instantiated five times, hipcc once kept the whole block in scratch memory)
     uint64_t *const g_fb = a.f.fb, *const g_rg = a.f.rg, *const g_ba = a.f.ba;
+    uint8_t *const g_tiles = a.f.tiles;
+    const uint32_t tiles_x = a.f.tiles_x;
     const int img_w = a.p.width;
     const uint32_t fb_elems = a.f.fb_elems;
     const float m00 = a.p.transform[0], m01 = a.p.transform[1], m02 = a.p.transform[2], m03 = a.p.transform[3];
@@ -1202,6 +1238,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     bool pend_valid = false, pend_off = false;              // (colour pass)
     uint64_t pend_off_mask = 0;                             // basic / depth pass: lanes whose pending point is inside the frustum but outside its window
+    const uint32_t whole_x0 = plan_p->whole_xy & 0xFFFFu, whole_y0 = plan_p->whole_xy >> 16;
+    const uint32_t whole_w = plan_p->whole_wh & 0xFFFFu, whole_h = plan_p->whole_wh >> 16;
     uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     lds_u64 *const s_win_mine = (lds_u64 *)(s_win + wbase); // my run's window
@@ -1463,8 +1501,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 pend_depth = __float_as_uint(qw);                                       // :287
                 pend_p = s_win_mine + (__builtin_amdgcn_inverse_ballot_w64(in_mask) ? (uint32_t)__umul24(ry, ww) + rx : dummy_idx);
                 pend_old = *pend_p;
+                uint64_t stray_now = 0;
+                if (pend_off_mask != 0) {
+                    // (uniform, rare) is one of them outside the rectangle the prepass marked the dirty tiles under as well (FrameView::tiles)?
+                    // The garbage tails of chains are: a thousandth of the points, anywhere on the screen. Whole-wave compares
+                    // under a scalar branch: a mask updated inside the divergent branch below is no longer uniform -- and the packed-words
+                    // variant then drew wrong frames (round 3; convergent operations in divergent control flow).
+                    stray_now = g_tiles ? pend_off_mask & (__builtin_amdgcn_ballot_w64((uint32_t)ix - whole_x0 >= whole_w) |
+                                                           __builtin_amdgcn_ballot_w64((uint32_t)iy - whole_y0 >= whole_h)) : 0;
+                }
                 if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) {   // (rare: the window plan keeps nearly every point inside)
                     pend_pix = (uint32_t)(ix + iy * img_w);                             // :285
+                    if (__builtin_amdgcn_inverse_ballot_w64(stray_now)) {
+                        // its own tile (ndc == 1.0 maps to column W, Appendix C.2: in the linear framebuffer that is column 0 of the next row)
+                        const uint32_t mx = ix >= img_w ? 0u : (uint32_t)ix, my = ix >= img_w ? (uint32_t)iy + 1u : (uint32_t)iy;
+                        g_tiles[(my >> TILE_H_SHIFT) * tiles_x + (mx >> TILE_W_SHIFT)] = 1;
+                    }
                     // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
                     // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
                     pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1765,6 +1817,20 @@ __global__ void __launch_bounds__(256) k_las_resolve(int width, int height, cons
 // CLEAR block (huffman_hqs.h:266-270): fb <- all ones, and RG/BA <- 0 when a colour pass has written them; one launch,
 // 16-byte stores
 // ------------------------------------------------------------------------------------------------
+// Tile flags at a CLEAR (FrameView::tiles): the half the coming frame marks starts empty; the other half -- tiles whose image pixels
+// may hold something -- takes over what was marked so far (a separate resolve may have drawn it), or everything if nobody kept track.
+struct TileFlags { uint8_t *cur, *prev; uint32_t *cur_all, *prev_all; uint32_t ntiles, e_cur, e_prev; int tracked; };
+__device__ __forceinline__ void clear_tile_flags(const TileFlags &t)
+{
+    if (!t.cur) return;
+    for (uint32_t i = threadIdx.x; i < t.ntiles; i += blockDim.x) {
+        t.prev[i] = t.tracked ? (uint8_t)(t.prev[i] | t.cur[i]) : (uint8_t)1;
+        t.cur[i] = 0;
+    }
+    // ("everything": the host gives the emptied half a fresh epoch, so its word needs no reset)
+    if (threadIdx.x == 0 && (!t.tracked || *t.cur_all == t.e_cur)) *t.prev_all = t.e_prev;
+}
+
 __device__ __forceinline__ void clear_block(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty,
                                             uint32_t block, uint32_t blocks)
 {
@@ -1782,19 +1848,21 @@ __device__ __forceinline__ void clear_block(uint64_t *fb, uint64_t *rg, uint64_t
     }
 }
 
-__global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty)
+__global__ void __launch_bounds__(256) k_clear(uint64_t *fb, uint64_t *rg, uint64_t *ba, size_t n, uint64_t empty, TileFlags tiles)
 {
     clear_block(fb, rg, ba, n, empty, blockIdx.x, gridDim.x);
+    if (blockIdx.x == gridDim.x - 1) clear_tile_flags(tiles);
 }
 
 // CLEAR and the prepass of the frame's first pass in one launch (pcr_frame_begin): the first `prepass_blocks` workgroups
 // do the cull/LOD work (it touches no framebuffer), the others fill. Saves the prepass's 5 us and a launch gap per frame.
 static_assert(PREPASS_THREADS == 256, "k_frame_begin runs both bodies with 256 threads");
 __global__ void __launch_bounds__(256) k_frame_begin(RenderArgs a, uint32_t prepass_blocks, uint64_t *fb, uint64_t *rg,
-                                                     uint64_t *ba, size_t n, uint64_t empty)
+                                                     uint64_t *ba, size_t n, uint64_t empty, TileFlags tiles)
 {
-    if (blockIdx.x < prepass_blocks) lod_prepass_block(a, blockIdx.x);
-    else clear_block(fb, rg, ba, n, empty, blockIdx.x - prepass_blocks, gridDim.x - prepass_blocks);
+    if (blockIdx.x < prepass_blocks) { lod_prepass_block(a, blockIdx.x); return; }
+    clear_block(fb, rg, ba, n, empty, blockIdx.x - prepass_blocks, gridDim.x - prepass_blocks);
+    if (blockIdx.x == gridDim.x - 1) clear_tile_flags(tiles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1919,9 +1987,12 @@ __global__ void __launch_bounds__(256) k_resolve(int show_num_points, int colori
 template <bool HQS>
 __global__ void __launch_bounds__(256) k_frame_turn(RenderArgs a, uint32_t prepass_blocks, int show_num_points, int colorize_chunks,
                                                     uint32_t pixels, uint64_t *fb, uint64_t *rg, uint64_t *ba, uint32_t *rgba,
-                                                    uint32_t n, uint64_t empty)
+                                                    uint32_t n, uint64_t empty, TileFlags tiles)
 {
     if (blockIdx.x < prepass_blocks) { lod_prepass_block(a, blockIdx.x); return; }
+    // (the whole frame is resolved and cleared: from here on the tile flags can be kept again -- nothing written yet, any image
+    // pixel may hold something)
+    if (blockIdx.x == gridDim.x - 1) { TileFlags t = tiles; t.tracked = 0; clear_tile_flags(t); }
     const uint32_t stride = (gridDim.x - prepass_blocks) * 256u;
     for (uint32_t i = (blockIdx.x - prepass_blocks) * 256u + threadIdx.x; i < n; i += stride) {
         if (i < pixels) {
@@ -1947,6 +2018,60 @@ __global__ void __launch_bounds__(256) k_frame_turn(RenderArgs a, uint32_t prepa
         }
         fb[i] = empty;
         if (HQS) { rg[i] = 0; ba[i] = 0; }
+    }
+}
+
+// The same over the dirty tiles only (FrameView::tiles). `cur`: tiles a framebuffer word was written in during the finished frame
+// -> resolved and cleared; `prev`: tiles whose image pixels may still hold something of the frame before -> background colour
+// again, unless they are dirty now. A workgroup takes whole tiles (256 threads x 4 pixels), reads its tile's two flags, and
+// leaves `prev` zeroed. Three arrays rotate: this launch's own prepass blocks mark the tiles of the NEXT frame in a third one
+// (all zero since the turn before), `cur` is what the next turn reads as its `prev`, the zeroed `prev` is marked by the frame after.
+template <bool HQS>
+__global__ void __launch_bounds__(256) k_frame_turn_tiles(RenderArgs a, uint32_t prepass_blocks, int show_num_points, int colorize_chunks,
+                                                          uint32_t width, uint32_t pixels, uint64_t *fb, uint64_t *rg, uint64_t *ba, uint32_t *rgba,
+                                                          uint32_t n, uint64_t empty, TileFlags tf, uint32_t tiles_x)
+{
+    if (blockIdx.x < prepass_blocks) { lod_prepass_block(a, blockIdx.x); return; }
+    const uint8_t *cur = tf.cur;
+    uint8_t *prev = tf.prev;
+    const uint32_t ntiles = tf.ntiles;
+    const uint32_t row = threadIdx.x >> 4, col = (threadIdx.x & 15u) * 4u;
+    const bool all_dirty = *tf.cur_all == tf.e_cur, all_was = *tf.prev_all == tf.e_prev;
+    for (uint32_t t = blockIdx.x - prepass_blocks; t < ntiles; t += gridDim.x - prepass_blocks) {       // (uniform)
+        const bool dirty = all_dirty || cur[t] != 0, was = all_was || prev[t] != 0;
+        if (!dirty && !was) continue;
+        const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+        const uint32_t x = (tx << TILE_W_SHIFT) + col, y = (ty << TILE_H_SHIFT) + row;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = y * width + x + k;
+            if (x + k >= width || i >= n) continue;
+            if (!dirty) { if (i < pixels) rgba[i] = PCR_BACKGROUND_COLOR; continue; }
+            if (i < pixels) {
+                const uint32_t id = (uint32_t)fb[i];
+                uint32_t color = PCR_BACKGROUND_COLOR;
+                if (id < 0xFFFFFFFFu) {
+                    if (show_num_points) {
+                        const double div = HQS ? 512.0 : 64.0;
+                        const uint32_t shade = (uint32_t)(((double)(float)(int)id / div) * 255.0);
+                        color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+                    } else if (colorize_chunks) {
+                        color = id * 1234567u;
+                    } else if (HQS) {
+                        const uint64_t vrg = rg[i], vba = ba[i];
+                        const uint32_t cnt = (uint32_t)vba;
+                        if (cnt == 0) color = 0;
+                        else color = (((uint32_t)(vba >> 32) / cnt) << 16) | (((uint32_t)vrg / cnt) << 8) | ((uint32_t)(vrg >> 32) / cnt);
+                    } else {
+                        color = id;
+                    }
+                }
+                rgba[i] = color;
+            }
+            fb[i] = empty;
+            if (HQS) { rg[i] = 0; ba[i] = 0; }
+        }
+        if (threadIdx.x == 0 && was) prev[t] = 0;
     }
 }
 
