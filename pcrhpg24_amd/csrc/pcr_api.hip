@@ -277,7 +277,7 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
     a.f.tiles = c->tiles_usable() && c->tiles_tracked ? c->tiles_half(c->tile_cur) : nullptr;
     a.f.tiles_all = c->d_tiles ? c->tiles_all(c->tile_cur) : nullptr;
-    a.f.tiles_x = c->tiles_x; a.f.tiles_epoch = c->tile_e_cur;
+    a.f.tiles_x = c->tiles_x; a.f.tiles_epoch = c->tile_e_cur; a.f.tiles_total = c->ntiles;
     a.lod = c->d_lod; a.win = c->d_win; a.win_hqs = nullptr; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
     a.order = c->d_order;
     a.chunk_count = c->d_chunk_count;
@@ -480,7 +480,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r03.v88"; }
+const char *pcr_kernel_version(void) { return "r03.v89"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -1202,7 +1202,7 @@ int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
     a.p = *p;
     a.s.batches = c->d_xyzb; a.s.xyz12 = c->d_xyz12; a.s.xyz8 = c->d_xyz8; a.s.xyz4 = c->d_xyz4; a.s.num_batches = nB;
     a.f.fb = c->fb; a.f.rg = c->rg; a.f.ba = c->ba; a.f.fb_elems = (uint32_t)c->fb_elems;
-    a.f.tiles = nullptr; a.f.tiles_all = nullptr; a.f.tiles_x = 0; a.f.tiles_epoch = 0;
+    a.f.tiles = nullptr; a.f.tiles_all = nullptr; a.f.tiles_x = 0; a.f.tiles_epoch = 0; a.f.tiles_total = 0;
     c->tiles_tracked = false;        // (this method's kernels do not mark tiles)
     a.level = c->d_las_level; a.win = c->d_las_win; a.stats = c->d_stats; a.win_capacity = WIN_PIXELS;
     c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);

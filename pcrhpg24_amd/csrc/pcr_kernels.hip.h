@@ -153,7 +153,7 @@ struct FrameView {
     // point loop, with a load in front of the store, cost the loop 6 % for code it practically never runs; profiles/r03_experiments.md.)
     uint8_t  *tiles;                  // [ntiles]
     uint32_t *tiles_all;              // "everything": holds tiles_epoch if so (an epoch per frame: the word never has to be zeroed)
-    uint32_t  tiles_x, tiles_epoch;
+    uint32_t  tiles_x, tiles_epoch, tiles_total;
 };
 constexpr uint32_t TILE_W_SHIFT = 6, TILE_H_SHIFT = 4;     // 64 x 16 pixels: a tile row is 512 contiguous bytes of the framebuffer
 
@@ -427,9 +427,16 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
             rect_pack(whole, wxy, wwh);
             const uint32_t tx0 = (uint32_t)whole.x0 >> TILE_W_SHIFT, ty0 = (uint32_t)whole.y0 >> TILE_H_SHIFT;
             const uint32_t ntx = ((uint32_t)whole.x1 >> TILE_W_SHIFT) - tx0 + 1u, nty = ((uint32_t)whole.y1 >> TILE_H_SHIFT) - ty0 + 1u;
-            for (uint32_t t = (uint32_t)r; t < ntx * nty; t += RUNS) {
-                const uint32_t ty = t / ntx, tx = t - ty * ntx;
-                a.f.tiles[(ty0 + ty) * a.f.tiles_x + tx0 + tx] = 1;
+            if (ntx * nty * 4u > a.f.tiles_total) {
+                // a batch that close to the camera covers a quarter of the screen or more: "everything", and the turn walks the frame linearly
+                if (r == 0) *a.f.tiles_all = a.f.tiles_epoch;
+            } else {
+                for (uint32_t ty = (uint32_t)r; ty < nty; ty += RUNS) {                  // a row of tiles per lane and turn
+                    uint8_t *row = a.f.tiles + (ty0 + ty) * a.f.tiles_x + tx0, *end = row + ntx;
+                    while (row < end && ((uintptr_t)row & 3u)) *row++ = 1;
+                    for (; row + 4 <= end; row += 4) *(uint32_t *)row = 0x01010101u;
+                    while (row < end) *row++ = 1;
+                }
             }
         } else if (r == 0) {
             *a.f.tiles_all = a.f.tiles_epoch;
@@ -2037,8 +2044,39 @@ __global__ void __launch_bounds__(256) k_frame_turn_tiles(RenderArgs a, uint32_t
     const uint32_t ntiles = tf.ntiles;
     const uint32_t row = threadIdx.x >> 4, col = (threadIdx.x & 15u) * 4u;
     const bool all_dirty = *tf.cur_all == tf.e_cur, all_was = *tf.prev_all == tf.e_prev;
+    if (all_dirty) {
+        // everything: the frame as k_frame_turn walks it (linear, 8-byte loads side by side), and `prev` zeroed on the way
+        const uint32_t stride = (gridDim.x - prepass_blocks) * 256u, first = (blockIdx.x - prepass_blocks) * 256u + threadIdx.x;
+        for (uint32_t t = first; t < ntiles; t += stride) prev[t] = 0;
+        for (uint32_t i = first; i < n; i += stride) {
+            if (i < pixels) {
+                const uint32_t id = (uint32_t)fb[i];
+                uint32_t color = PCR_BACKGROUND_COLOR;
+                if (id < 0xFFFFFFFFu) {
+                    if (show_num_points) {
+                        const double div = HQS ? 512.0 : 64.0;
+                        const uint32_t shade = (uint32_t)(((double)(float)(int)id / div) * 255.0);
+                        color = (shade << 24) | (shade << 16) | (shade << 8) | shade;
+                    } else if (colorize_chunks) {
+                        color = id * 1234567u;
+                    } else if (HQS) {
+                        const uint64_t vrg = rg[i], vba = ba[i];
+                        const uint32_t cnt = (uint32_t)vba;
+                        if (cnt == 0) color = 0;
+                        else color = (((uint32_t)(vba >> 32) / cnt) << 16) | (((uint32_t)vrg / cnt) << 8) | ((uint32_t)(vrg >> 32) / cnt);
+                    } else {
+                        color = id;
+                    }
+                }
+                rgba[i] = color;
+            }
+            fb[i] = empty;
+            if (HQS) { rg[i] = 0; ba[i] = 0; }
+        }
+        return;
+    }
     for (uint32_t t = blockIdx.x - prepass_blocks; t < ntiles; t += gridDim.x - prepass_blocks) {       // (uniform)
-        const bool dirty = all_dirty || cur[t] != 0, was = all_was || prev[t] != 0;
+        const bool dirty = cur[t] != 0, was = all_was || prev[t] != 0;
         if (!dirty && !was) continue;
         const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
         const uint32_t x = (tx << TILE_W_SHIFT) + col, y = (ty << TILE_H_SHIFT) + row;
