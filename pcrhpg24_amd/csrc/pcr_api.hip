@@ -360,6 +360,9 @@ int enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
 // bound by global pre-reads and atomics; one workgroup per CU with windows of ~17 000 pixels keeps them in LDS.
 uint32_t frame_dyn_lds(const pcr_ctx *c, int64_t nB)
 {
+    static const char *force = getenv("PCR_EXP_DYN_LDS");              // experiments: "small" / "big"
+    if (force && force[0] == 's') return (uint32_t)DYN_LDS_BYTES;
+    if (force && force[0] == 'b') return (uint32_t)DYN_LDS_BYTES_BIG;
     return (int64_t)c->width * c->height > nB * (int64_t)WIN_PIXELS ? (uint32_t)DYN_LDS_BYTES_BIG : (uint32_t)DYN_LDS_BYTES;
 }
 

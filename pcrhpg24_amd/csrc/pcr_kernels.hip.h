@@ -1105,7 +1105,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // (per-lane byte offsets that advance by a row: with a uniform pointer that advances instead, hipcc adds the lane's
     // offset to it with a 64-bit vector add in front of every load)
     auto pw_load_hi = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pwb + byte_off); };
+#ifdef PCR_EXP_NO_LO      // timing experiment only (wrong frames): what 32-bit windows would save -- the low plane is never read
+    auto pw_load_lo = [&](uint32_t) -> uint32_t { return 0u; };
+#else
     auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint8_t *>(pwb + byte_off); };
+#endif
     uint32_t lwo = LAYOUT == LAYOUT_WORDS ? (tid & 63u) * 4 : tid * 4;     // byte offset of my column in the row of far0 / in the high plane's row
     uint32_t lwo2 = PW_HI_BYTES + tid;                      // ... in the low plane's row
     uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
@@ -1209,10 +1213,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // Scalar instructions are not free here (+16 of them per point: +6 % kernel time, profiles/r03_experiments.md): lane masks
     // carried as 64-bit values and tested as such cost a compare and a branch, bools carried across the loop cost three
     // mask merges each.
-    auto scatter_min = [&](__attribute__((address_space(3))) unsigned long long *wp, uint32_t depth, uint64_t old, uint64_t off_mask, uint32_t pix, int point) __attribute__((always_inline)) {
+    auto scatter_min = [&](__attribute__((address_space(3))) unsigned long long *wp, uint32_t depth, uint32_t old_hi, uint64_t off_mask, uint32_t pix, int point) __attribute__((always_inline)) {
         // pre-read filter (:297-298) on the depth half only: the result is min(depth<<32|payload) over all inside points
         // whatever passes it (min is idempotent), so ties go to the atomic instead of a 64-bit compare here
-        if (depth > (uint32_t)(old >> 32)) return;
+        if (depth > old_hi) return;
         const unsigned long long key = ((unsigned long long)depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)point & 15u) : payload);   // :299 / depth.cu:139-145
         __hip_atomic_fetch_min(wp, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__builtin_amdgcn_inverse_ballot_w64(off_mask)) atomicMin((unsigned long long *)&g_fb[pix], key);   // :300 (rare)
@@ -1253,7 +1257,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     lds_u64 *const s_dummy = (lds_u64 *)(s_win + wpix);     // (see the window's set-up)
     const uint32_t dummy_idx = wpix - wbase;                // ... as an index into my run's window
     lds_u64 *pend_p = s_dummy;                              // basic / depth pass: the pending point's word in the LDS window
-    uint64_t pend_old = 0;
+    uint64_t pend_old = 0;                                  // (colour pass)
+    uint32_t pend_old_hi = 0;                               // basic / depth pass: the depth half of the pending point's framebuffer word
 
     const float *M = a.p.transform;
     const float fw = (float)a.p.width, fh = (float)a.p.height;
@@ -1283,6 +1288,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     uint32_t sft_ahead = SFT0 - e_ahead;                    // :439 (the whole entry: byte 0 is the length)
     uint32_t toff1_ahead = ((uint32_t)(bits >> 32) >> (sft_ahead & 31u)) & 0x3FFCu;
     uint32_t e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
+    // DECODE_AHEAD (point windows, basic / depth pass): all three entries of a point are requested during the iteration before
+    // it, spread over that iteration (see the loop); these are the ones of point 0
+    constexpr bool DECODE_AHEAD = LAYOUT == LAYOUT_POINT_WINDOWS && !COLOR_PASS;
+    uint32_t toff2_ahead = 0, e2_ahead = 0;
+    if (DECODE_AHEAD) {
+        toff2_ahead = (uint32_t)(bits >> ((sft_ahead - e1_ahead) & 63u)) & 0x3FFCu;
+        e2_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff2_ahead);
+    }
 
     // ---- the point loop ---------------------------------------------------------------------------------------------------------
     // A wave issues in order and the decode is a chain of LDS round trips (table entry -> length -> next key -> next
@@ -1367,7 +1380,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
       if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, seg - 1); pend_valid = false; }
-      else { scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, seg - 1); pend_p = s_dummy; pend_old = 0; pend_off_mask = 0; }
+      else { scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, seg - 1); pend_p = s_dummy; pend_off_mask = 0;
+             // (the dummy slot's zero, READ rather than set: with an LDS read behind the last table request on this way into the loop
+             // as well as on the way round it, hipcc's wait for that entry at the top of an iteration leaves one result in flight)
+             pend_old_hi = reinterpret_cast<__attribute__((address_space(3))) const volatile uint32_t *>(s_dummy)[1]; }
       if (MODE != MODE_HQS_DEPTH) {
           if (BC7) pal7 = bc7_block(blocks7[(seg >> 4) * PCR_WORKGROUP_SIZE]);
           else {
@@ -1405,7 +1421,43 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         }
 #endif
         uint32_t d0, d1, d2;
-        if (LAYOUT == LAYOUT_POINT_WINDOWS) {
+        uint32_t sft1_next = 0;
+        if (DECODE_AHEAD) {
+            // All three table entries of point i were requested while point i-1 was projected: nothing of the decode's dependent
+            // chain (entry -> length -> key -> entry) is waited for here. The escape words of the three symbols, if any, are
+            // requested back to back; the scatter of point i-1 runs under them. The entries of point i+1 (its window has been in
+            // registers since the top of the last iteration) are requested in three places of this iteration, each a table
+            // round trip after the one before: here, in front of the dot products, behind the division.
+            const uint32_t e0 = e_ahead, toff0 = toff_ahead, e1 = e1_ahead, toff1 = toff1_ahead, e2 = e2_ahead, toff2 = toff2_ahead;
+            if (!GENERIC) {
+                // Everything that hangs on a result of the last iteration -- the three entries, the framebuffer word of point i-1 --
+                // is looked at BEFORE this iteration issues its first LDS instruction: results return in issue order and hipcc
+                // counts a read under a branch (an escape word's) as maybe not issued, so a wait placed behind such reads waits for
+                // them as well. What is tested becomes a lane mask in a scalar register pair.
+                int32_t v0 = (int32_t)e0 >> TE_VALUE_SHIFT, v1 = (int32_t)e1 >> TE_VALUE_SHIFT, v2 = (int32_t)e2 >> TE_VALUE_SHIFT;
+                const uint64_t esc0 = __builtin_amdgcn_ballot_w64(v0 == TE_SLOW_VALUE), esc1 = __builtin_amdgcn_ballot_w64(v1 == TE_SLOW_VALUE),
+                               esc2 = __builtin_amdgcn_ballot_w64(v2 == TE_SLOW_VALUE);
+                const uint64_t draw = __builtin_amdgcn_ballot_w64(pend_depth <= pend_old_hi);     // the pre-read filter of scatter_min
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc0), 1)) v0 = *esc_next++;               // :438 (every such entry is an escape whose word is in the pool)
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc1), 1)) v1 = *esc_next++;
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc2), 1)) v2 = *esc_next++;
+                toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
+                e_ahead = table_entry(toff_ahead);
+                if (__builtin_amdgcn_inverse_ballot_w64(draw)) {                                // second half of rasterize() for point i-1
+                    const unsigned long long key = ((unsigned long long)pend_depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)(i - 1) & 15u) : payload);
+                    __hip_atomic_fetch_min(pend_p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) atomicMin((unsigned long long *)&g_fb[pend_pix], key);   // :300 (rare)
+                }
+                d0 = (uint32_t)v0; d1 = (uint32_t)v1; d2 = (uint32_t)v2;
+            } else {
+                d0 = entry_value(e0, toff0);                                    // :430
+                d1 = entry_value(e1, toff1);
+                d2 = entry_value(e2, toff2);
+                toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
+                e_ahead = table_entry(toff_ahead);
+                scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
+            }
+        } else if (LAYOUT == LAYOUT_POINT_WINDOWS) {
             // The first symbol's key is the top of the point's own window: its entry was requested a whole point ago (the one of
             // point i+1, whose window is already in registers, is requested now). The second symbol's entry was requested before
             // the point began as well: at the end of the iteration before, as soon as the first entry gave the second key (the
@@ -1420,7 +1472,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             // second half of rasterize() for point i-1, under the table read of this point's second symbol: its framebuffer
             // word has been in flight since the end of the last iteration
             // (the colour pass, which carries a run of sums and has no register to spare, scatters after the third symbol)
-            if (!COLOR_PASS) scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, i - 1);
+            if (!COLOR_PASS) scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
             sft -= e1;
             const uint32_t toff2 = (uint32_t)(bits >> (sft & 63u)) & 0x3FFCu;
             const uint32_t e2 = table_entry(toff2);
@@ -1430,7 +1482,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             constexpr std::integral_constant<bool, false> table_first{};
             constexpr std::integral_constant<bool, true> escape_first{};
             d0 = symbol_step(table_first);                                  // :430
-            if (!COLOR_PASS) scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, i - 1);
+            if (!COLOR_PASS) scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
             d1 = symbol_step(table_first);
             d2 = symbol_step(escape_first);
         }
@@ -1507,7 +1559,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 pend_off_mask = cand_mask & ~in_mask;
                 pend_depth = __float_as_uint(qw);                                       // :287
                 pend_p = s_win_mine + (__builtin_amdgcn_inverse_ballot_w64(in_mask) ? (uint32_t)__umul24(ry, ww) + rx : dummy_idx);
-                pend_old = *pend_p;
+                // (the depth half alone: the filter looks at nothing else, and a 64-bit read whose low half nobody wants had hipcc reuse
+                // that register while the read was in flight -- and wait for it)
+                pend_old_hi = reinterpret_cast<__attribute__((address_space(3))) const uint32_t *>(pend_p)[1];
                 uint64_t stray_now = 0;
                 if (pend_off_mask != 0) {
                     // (uniform, rare) is one of them outside the rectangle the prepass marked the dirty tiles under as well (FrameView::tiles)?
@@ -1526,7 +1580,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     }
                     // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
                     // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
-                    pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    pend_old_hi = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&g_fb[pend_pix]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 return;
             }
@@ -1556,15 +1610,24 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             fy = (float)__fma_rn((double)py, sy, oy);
             fz = (float)__fma_rn((double)pz, sz, oz);
         }
+        if (DECODE_AHEAD) {                         // second entry of point i+1 (`bits` is its window by now; the first has arrived)
+            sft1_next = SFT0 - e_ahead;
+            toff1_ahead = ((uint32_t)(bits >> 32) >> (sft1_next & 31u)) & 0x3FFCu;
+            e1_ahead = table_entry(toff1_ahead);
+        }
         project_dots();                                                     // first half of rasterize() (:278-287) for point i
         project_divide();
+        if (DECODE_AHEAD) {                         // third entry of point i+1
+            toff2_ahead = (uint32_t)(bits >> ((sft1_next - e1_ahead) & 63u)) & 0x3FFCu;
+            e2_ahead = table_entry(toff2_ahead);
+        }
 #ifdef PCR_EXP_NO_FBLOAD   /* experiment only: decode + projection, no framebuffer traffic (results are wrong) */
         if (inside && ix == 0x12345678) g_fb[tid] = __float_as_uint(qw);
-        pend_valid = false; pend_p = s_dummy; pend_old = 0; pend_off_mask = 0;
+        pend_valid = false; pend_p = s_dummy; pend_old_hi = 0; pend_off_mask = 0;
 #else
         project_request();
 #endif
-        if (LAYOUT == LAYOUT_POINT_WINDOWS) {       // `bits` is the next point's window by now, e_ahead its first entry (requested at the top)
+        if (LAYOUT == LAYOUT_POINT_WINDOWS && !DECODE_AHEAD) {       // `bits` is the next point's window by now, e_ahead its first entry (requested at the top)
             sft_ahead = SFT0 - e_ahead;
             toff1_ahead = ((uint32_t)(bits >> 32) >> (sft_ahead & 31u)) & 0x3FFCu;
             e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
@@ -1573,7 +1636,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
       }
     }
     if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, npr_run - 1); flush_run(); }
-    else scatter_min(pend_p, pend_depth, pend_old, pend_off_mask, pend_pix, npr_run - 1);
+    else scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, npr_run - 1);
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
