@@ -1176,23 +1176,27 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // and `old` came from global memory). Both are lane masks the compiler keeps in scalar registers, so choosing between the
     // LDS and the global path costs no vector instruction. The window word of the pixel: `wp` (basic / depth pass) or the
     // index `w` (colour pass: three planes).
+    // colour pass: the contribution of a point that passed the 1 % test (hqs render.cu:297-313)
+    auto accumulate = [&](bool off, uint32_t pix, uint32_t w, int point) __attribute__((always_inline)) {
+        const uint32_t rgba = BC7 ? bc7_color(pal7, (uint32_t)point & 15u) : bc1_color(pal, (uint32_t)point & 15u);
+        const uint32_t vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);   // r << 16 | g  (rgba = 0x00BBGGRR)
+        const uint32_t vbc = (rgba & 0x00FF0000u) | 1u;                        // b << 16 | 1
+        // Consecutive points of a chain are Morton neighbours and mostly land in the same pixel: their
+        // contributions are summed in registers and written once per run (sums commute, so the totals
+        // are unchanged; a chain adds at most 64 * 255 per 32-bit half).
+        if (pix == run_pix) {
+            run_rg16 += vrg; run_bc16 += vbc;
+        } else {
+            flush_run();
+            run_pix = pix; run_widx = off ? NO_PIXEL : w; run_rg16 = vrg; run_bc16 = vbc;
+        }
+    };
     auto scatter = [&](bool valid, bool off, uint32_t pix, uint32_t w, unsigned long long *wp, uint32_t depth, uint64_t old, int point) __attribute__((always_inline)) {
         if (COLOR_PASS) {
             const float pw = __uint_as_float(depth);
             const float old_depth = __uint_as_float((uint32_t)(old >> 32));
             if (valid && (double)pw <= (double)old_depth * 1.01) {          // hqs render.cu:296
-                const uint32_t rgba = BC7 ? bc7_color(pal7, (uint32_t)point & 15u) : bc1_color(pal, (uint32_t)point & 15u);
-                const uint32_t vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);   // r << 16 | g  (rgba = 0x00BBGGRR)
-                const uint32_t vbc = (rgba & 0x00FF0000u) | 1u;                        // b << 16 | 1
-                // Consecutive points of a chain are Morton neighbours and mostly land in the same pixel: their
-                // contributions are summed in registers and written once per run (sums commute, so the totals
-                // are unchanged; a chain adds at most 64 * 255 per 32-bit half).
-                if (pix == run_pix) {
-                    run_rg16 += vrg; run_bc16 += vbc;
-                } else {
-                    flush_run();
-                    run_pix = pix; run_widx = off ? NO_PIXEL : w; run_rg16 = vrg; run_bc16 = vbc;
-                }
+                accumulate(off, pix, w, point);
             }
             return;
         }
@@ -1290,7 +1294,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     uint32_t e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
     // DECODE_AHEAD (point windows, basic / depth pass): all three entries of a point are requested during the iteration before
     // it, spread over that iteration (see the loop); these are the ones of point 0
-    constexpr bool DECODE_AHEAD = LAYOUT == LAYOUT_POINT_WINDOWS && !COLOR_PASS;
+    constexpr bool DECODE_AHEAD = LAYOUT == LAYOUT_POINT_WINDOWS;
     uint32_t toff2_ahead = 0, e2_ahead = 0;
     if (DECODE_AHEAD) {
         toff2_ahead = (uint32_t)(bits >> ((sft_ahead - e1_ahead) & 63u)) & 0x3FFCu;
@@ -1437,13 +1441,18 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 int32_t v0 = (int32_t)e0 >> TE_VALUE_SHIFT, v1 = (int32_t)e1 >> TE_VALUE_SHIFT, v2 = (int32_t)e2 >> TE_VALUE_SHIFT;
                 const uint64_t esc0 = __builtin_amdgcn_ballot_w64(v0 == TE_SLOW_VALUE), esc1 = __builtin_amdgcn_ballot_w64(v1 == TE_SLOW_VALUE),
                                esc2 = __builtin_amdgcn_ballot_w64(v2 == TE_SLOW_VALUE);
-                const uint64_t draw = __builtin_amdgcn_ballot_w64(pend_depth <= pend_old_hi);     // the pre-read filter of scatter_min
+                // the pre-read filter of scatter_min / the 1 % test of the colour pass (hqs render.cu:296)
+                const uint64_t draw = COLOR_PASS
+                    ? __builtin_amdgcn_ballot_w64(pend_valid && (double)__uint_as_float(pend_depth) <= (double)__uint_as_float((uint32_t)(pend_old >> 32)) * 1.01)
+                    : __builtin_amdgcn_ballot_w64(pend_depth <= pend_old_hi);
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc0), 1)) v0 = *esc_next++;               // :438 (every such entry is an escape whose word is in the pool)
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc1), 1)) v1 = *esc_next++;
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc2), 1)) v2 = *esc_next++;
                 toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
                 e_ahead = table_entry(toff_ahead);
-                if (__builtin_amdgcn_inverse_ballot_w64(draw)) {                                // second half of rasterize() for point i-1
+                if (COLOR_PASS) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(draw)) accumulate(pend_off, pend_pix, pend_w, i - 1);
+                } else if (__builtin_amdgcn_inverse_ballot_w64(draw)) {                         // second half of rasterize() for point i-1
                     const unsigned long long key = ((unsigned long long)pend_depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)(i - 1) & 15u) : payload);
                     __hip_atomic_fetch_min(pend_p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) atomicMin((unsigned long long *)&g_fb[pend_pix], key);   // :300 (rare)
@@ -1455,7 +1464,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 d2 = entry_value(e2, toff2);
                 toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
                 e_ahead = table_entry(toff_ahead);
-                scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
+                if (COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
+                else scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
             }
         } else if (LAYOUT == LAYOUT_POINT_WINDOWS) {
             // The first symbol's key is the top of the point's own window: its entry was requested a whole point ago (the one of
@@ -1486,7 +1496,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             d1 = symbol_step(table_first);
             d2 = symbol_step(escape_first);
         }
-        if (COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
+        if (COLOR_PASS && !DECODE_AHEAD) scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
         pz = (int32_t)((uint32_t)pz + d2);
@@ -1562,25 +1572,24 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 // (the depth half alone: the filter looks at nothing else, and a 64-bit read whose low half nobody wants had hipcc reuse
                 // that register while the read was in flight -- and wait for it)
                 pend_old_hi = reinterpret_cast<__attribute__((address_space(3))) const uint32_t *>(pend_p)[1];
-                uint64_t stray_now = 0;
-                if (pend_off_mask != 0) {
-                    // (uniform, rare) is one of them outside the rectangle the prepass marked the dirty tiles under as well (FrameView::tiles)?
-                    // The garbage tails of chains are: a thousandth of the points, anywhere on the screen. Whole-wave compares
-                    // under a scalar branch: a mask updated inside the divergent branch below is no longer uniform -- and the packed-words
-                    // variant then drew wrong frames (round 3; convergent operations in divergent control flow).
-                    stray_now = g_tiles ? pend_off_mask & (__builtin_amdgcn_ballot_w64((uint32_t)ix - whole_x0 >= whole_w) |
-                                                           __builtin_amdgcn_ballot_w64((uint32_t)iy - whole_y0 >= whole_h)) : 0;
-                }
-                if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) {   // (rare: the window plan keeps nearly every point inside)
-                    pend_pix = (uint32_t)(ix + iy * img_w);                             // :285
-                    if (__builtin_amdgcn_inverse_ballot_w64(stray_now)) {
-                        // its own tile (ndc == 1.0 maps to column W, Appendix C.2: in the linear framebuffer that is column 0 of the next row)
-                        const uint32_t mx = ix >= img_w ? 0u : (uint32_t)ix, my = ix >= img_w ? (uint32_t)iy + 1u : (uint32_t)iy;
-                        g_tiles[(my >> TILE_H_SHIFT) * tiles_x + (mx >> TILE_W_SHIFT)] = 1;
+                if (__builtin_expect(pend_off_mask != 0, 0)) {              // (uniform, rare: the window plan keeps nearly every point inside)
+                    // Is one of them outside the rectangle the prepass marked the dirty tiles under as well (FrameView::tiles)? The
+                    // garbage tails of chains are: a thousandth of the points, anywhere on the screen. Whole-wave
+                    // compares under the scalar branch: a mask updated inside the divergent branch below is no longer uniform -- and
+                    // the packed-words variant then drew wrong frames (round 3; convergent operations in divergent control flow).
+                    const uint64_t stray_now = g_tiles ? pend_off_mask & (__builtin_amdgcn_ballot_w64((uint32_t)ix - whole_x0 >= whole_w) |
+                                                                          __builtin_amdgcn_ballot_w64((uint32_t)iy - whole_y0 >= whole_h)) : 0;
+                    if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) {
+                        pend_pix = (uint32_t)(ix + iy * img_w);                         // :285
+                        if (__builtin_amdgcn_inverse_ballot_w64(stray_now)) {
+                            // its own tile (ndc == 1.0 maps to column W, Appendix C.2: in the linear framebuffer that is column 0 of the next row)
+                            const uint32_t mx = ix >= img_w ? 0u : (uint32_t)ix, my = ix >= img_w ? (uint32_t)iy + 1u : (uint32_t)iy;
+                            g_tiles[(my >> TILE_H_SHIFT) * tiles_x + (mx >> TILE_W_SHIFT)] = 1;
+                        }
+                        // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
+                        // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
+                        pend_old_hi = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&g_fb[pend_pix]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
-                    // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
-                    // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
-                    pend_old_hi = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&g_fb[pend_pix]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 return;
             }
