@@ -1251,8 +1251,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         sft = SFT0;                                                                        \
     } while (0)
 
-    bool pend_valid = false, pend_off = false;              // (colour pass)
-    uint64_t pend_off_mask = 0;                             // basic / depth pass: lanes whose pending point is inside the frustum but outside its window
+    uint64_t pend_valid_mask = 0;                           // colour pass: lanes whose pending point is inside the frustum
+    uint64_t pend_off_mask = 0;                             // lanes whose pending point is inside the frustum but outside its window
     const uint32_t whole_x0 = plan_p->whole_xy & 0xFFFFu, whole_y0 = plan_p->whole_xy >> 16;
     const uint32_t whole_w = plan_p->whole_wh & 0xFFFFu, whole_h = plan_p->whole_wh >> 16;
     uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
@@ -1383,7 +1383,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #endif
       // Segment boundary: the point still pending belongs to the previous BC1 block, so it is scattered before the
       // block registers rotate (its framebuffer word has been in flight for the whole decode of the last point).
-      if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, seg - 1); pend_valid = false; }
+      if (COLOR_PASS) { scatter(__builtin_amdgcn_inverse_ballot_w64(pend_valid_mask), __builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, nullptr, pend_depth, pend_old, seg - 1); pend_valid_mask = 0; pend_off_mask = 0; }
       else { scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, seg - 1); pend_p = s_dummy; pend_off_mask = 0;
              // (the dummy slot's zero, READ rather than set: with an LDS read behind the last table request on this way into the loop
              // as well as on the way round it, hipcc's wait for that entry at the top of an iteration leaves one result in flight)
@@ -1443,7 +1443,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                                esc2 = __builtin_amdgcn_ballot_w64(v2 == TE_SLOW_VALUE);
                 // the pre-read filter of scatter_min / the 1 % test of the colour pass (hqs render.cu:296)
                 const uint64_t draw = COLOR_PASS
-                    ? __builtin_amdgcn_ballot_w64(pend_valid && (double)__uint_as_float(pend_depth) <= (double)__uint_as_float((uint32_t)(pend_old >> 32)) * 1.01)
+                    ? pend_valid_mask & __builtin_amdgcn_ballot_w64((double)__uint_as_float(pend_depth) <= (double)__uint_as_float((uint32_t)(pend_old >> 32)) * 1.01)
                     : __builtin_amdgcn_ballot_w64(pend_depth <= pend_old_hi);
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc0), 1)) v0 = *esc_next++;               // :438 (every such entry is an escape whose word is in the pool)
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc1), 1)) v1 = *esc_next++;
@@ -1451,7 +1451,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
                 e_ahead = table_entry(toff_ahead);
                 if (COLOR_PASS) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(draw)) accumulate(pend_off, pend_pix, pend_w, i - 1);
+                    if (__builtin_amdgcn_inverse_ballot_w64(draw)) accumulate(__builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, i - 1);
                 } else if (__builtin_amdgcn_inverse_ballot_w64(draw)) {                         // second half of rasterize() for point i-1
                     const unsigned long long key = ((unsigned long long)pend_depth << 32) | (MODE == MODE_BASIC ? bc1_color(pal, (uint32_t)(i - 1) & 15u) : payload);
                     __hip_atomic_fetch_min(pend_p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1464,7 +1464,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 d2 = entry_value(e2, toff2);
                 toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
                 e_ahead = table_entry(toff_ahead);
-                if (COLOR_PASS) scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
+                if (COLOR_PASS) scatter(__builtin_amdgcn_inverse_ballot_w64(pend_valid_mask), __builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
                 else scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
             }
         } else if (LAYOUT == LAYOUT_POINT_WINDOWS) {
@@ -1496,7 +1496,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             d1 = symbol_step(table_first);
             d2 = symbol_step(escape_first);
         }
-        if (COLOR_PASS && !DECODE_AHEAD) scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
+        if (COLOR_PASS && !DECODE_AHEAD) scatter(__builtin_amdgcn_inverse_ballot_w64(pend_valid_mask), __builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
         pz = (int32_t)((uint32_t)pz + d2);
@@ -1593,21 +1593,20 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 }
                 return;
             }
-            bool in_window = false, off_window = false;
-            if (inside) {
-                pend_depth = __float_as_uint(qw);                                       // :287
-                pend_pix = (uint32_t)(ix + iy * img_w);                     // the colour pass names its runs by pixel
-                const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
-                in_window = rx < ww && ry < wh;
-                off_window = !in_window;
-                // (an off-window point reads the window's first word: any valid address will do, its result is replaced below)
-                pend_w = wbase + (in_window ? ry * ww + rx : 0u);
-            }
-            pend_valid = inside;
-            pend_off = off_window;
-            // (every lane reads, wanted or not: see above)
+            // colour pass, the same without flags per lane: every lane works out a pixel and a window position (garbage for a lane
+            // that is not inside), the masks decide; a lane with no window word reads the window's first one (any valid address
+            // will do: its result is not looked at, or replaced below)
+            const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
+            const uint64_t in_mask = cand_mask & __builtin_amdgcn_ballot_w64(rx < ww) & __builtin_amdgcn_ballot_w64(ry < wh);
+            pend_valid_mask = cand_mask;
+            pend_off_mask = cand_mask & ~in_mask;
+            pend_depth = __float_as_uint(qw);                                           // :287
+            pend_pix = (uint32_t)(ix + iy * img_w);                         // the colour pass names its runs by pixel
+            pend_w = wbase + (__builtin_amdgcn_inverse_ballot_w64(in_mask) ? ry * ww + rx : 0u);
             pend_old = (uint64_t)s_depth[pend_w] << 32;
-            if (off_window) pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (__builtin_expect(pend_off_mask != 0, 0)) {
+                if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) pend_old = __hip_atomic_load(&g_fb[pend_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
         };
 
         // (the float form always, the double form as an override for the batches that want it: see project_divide)
@@ -1632,7 +1631,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         }
 #ifdef PCR_EXP_NO_FBLOAD   /* experiment only: decode + projection, no framebuffer traffic (results are wrong) */
         if (inside && ix == 0x12345678) g_fb[tid] = __float_as_uint(qw);
-        pend_valid = false; pend_p = s_dummy; pend_old_hi = 0; pend_off_mask = 0;
+        pend_valid_mask = 0; pend_p = s_dummy; pend_old_hi = 0; pend_off_mask = 0;
 #else
         project_request();
 #endif
@@ -1644,7 +1643,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo << 24; }
       }
     }
-    if (COLOR_PASS) { scatter(pend_valid, pend_off, pend_pix, pend_w, nullptr, pend_depth, pend_old, npr_run - 1); flush_run(); }
+    if (COLOR_PASS) { scatter(__builtin_amdgcn_inverse_ballot_w64(pend_valid_mask), __builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, nullptr, pend_depth, pend_old, npr_run - 1); flush_run(); }
     else scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, npr_run - 1);
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
