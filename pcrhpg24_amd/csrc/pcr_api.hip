@@ -51,7 +51,7 @@ struct pcr_ctx {
     uint32_t *d_batch_runs = nullptr;           // runs of chains and their bounding boxes, RUN_WORDS per batch (k_bounds)
     uint32_t *d_batch_flags = nullptr;          // BF_* per batch (k_transcode)
     // dense lists of the batches a frame draws, compacted by k_lod_prepass per workgroup (see RenderArgs): d_order[2][order_stride],
-    // d_chunk_count[2][PCR_MAX_PREPASS_WORKGROUPS]
+    // d_chunk_count[WORK_CLASSES + 1][PCR_MAX_PREPASS_WORKGROUPS]
     DrawRec *d_order = nullptr;
     uint32_t *d_chunk_count = nullptr;
     uint32_t order_stride = 0;
@@ -283,6 +283,7 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.chunk_count = c->d_chunk_count;
     // chunks of the batches this frame draws (the prepass of the frame covered exactly these)
     a.order_stride = (uint32_t)((a.s.num_batches + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES;
+    a.work_classes = a.s.num_batches > 8192 ? 1u : (uint32_t)WORK_CLASSES;
     return a;
 }
 
@@ -483,7 +484,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r03.v95"; }
+const char *pcr_kernel_version(void) { return "r03.v98"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -607,7 +608,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
         (rc = dalloc_zero(c, c->d_batch_runs, nB * RUN_WORDS, acc)) ||
         (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES, acc)) ||
-        (rc = dalloc_zero(c, c->d_chunk_count, 2 * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
+        (rc = dalloc_zero(c, c->d_chunk_count, (WORK_CLASSES + 1) * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
         (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc))) ||
         (words && ((rc = dalloc_zero(c, c->d_lw_block, nB, acc)) || (rc = dalloc_zero(c, c->d_lw_wave_row, nB * (LWC_WAVES + 1), acc)) ||
                    (rc = dalloc_zero(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES, acc))))) {

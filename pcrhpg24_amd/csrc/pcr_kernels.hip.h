@@ -194,8 +194,15 @@ struct RenderArgs {
     // with one atomic per workgroup: the chunks then land in arrival order, and the close-up frame, whose heavy batches
     // lead the file, ran 25 % longer with them shuffled.)
     struct DrawRec *order;    // [2][order_stride]
-    uint32_t *chunk_count;    // [2][PCR_MAX_PREPASS_WORKGROUPS]
+    uint32_t *chunk_count;    // [WORK_CLASSES + 1][PCR_MAX_PREPASS_WORKGROUPS]: the ordinary list's classes, then the checked list
     uint32_t order_stride;    // prepass workgroups * PREPASS_BATCHES
+    // Longest first: with a level of detail the batches of a frame decode 1..64 points per chain, a workgroup lives 20..55 us, and in
+    // the file's order the launch ends with a long tail of half-empty CUs (LOD 10 %: 153 us where the sum of the lifetimes over 512
+    // slots is 106). The ordinary list is therefore drawn class by class -- WORK_CLASSES classes of points per chain, heaviest
+    // first, the file's order inside a class: a chunk's records are stored class after class, chunk_count[class][chunk] counts them,
+    // and k_render's scan walks the classes in turn. A frame at LOD 100 % has one class and scans as before. work_classes: 1 for
+    // streams of more than 8192 batches (a scan round per 2048 batches AND class would cost their light workgroups more than it saves).
+    uint32_t work_classes;
     // A list entry is a record, not just the batch's index: what k_render's workgroup needs to know before it can request the
     // batch's data (level-of-detail word, escape count, escape offset). Its set-up is then three dependent memory levels (chunk
     // counts -> record -> data) instead of four (... -> list entry -> lod / batch header / escape count -> data): 7 us of a
@@ -230,6 +237,8 @@ __device__ __forceinline__ bool plane_accepts(float x, float y, float z, float w
 // nothing to zero beforehand); pcr_get_stats adds the partials of the last launch. PCR_STATS_PARTIALS bounds the grid.
 constexpr int PREPASS_THREADS = 256;
 constexpr int PCR_MAX_PREPASS_WORKGROUPS = 2048;        // ceil(65535 batches / 32 batches per prepass workgroup)
+constexpr int WORK_CLASSES = 4;                         // of the ordinary list, by points per chain: 49..64, 33..48, 17..32, 1..16 (RenderArgs::work_classes;
+                                                        // 2, 3 and 4 classes measure alike, 8 cost the light workgroups' scans more than they gain)
 __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_render_stats *partials)
 {
     __shared__ unsigned long long s_sum[4];
@@ -287,11 +296,21 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
             r.esc_total = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 1023];
             r.sep_off = a.s.batches[bb].separate_batch_offset;
         }
+        // the ordinary list: class after class inside the chunk
+        const uint32_t npr = r.lod & LOD_NPR_MASK;
+        const uint32_t cls = a.work_classes > 1 && npr ? (uint32_t)(WORK_CLASSES - 1) - min((npr - 1u) / (64u / WORK_CLASSES), (uint32_t)(WORK_CLASSES - 1)) : 0u;
+        uint32_t base = 0;
 #pragma unroll
-        for (uint32_t k = 1; k <= 2; ++k) {
-            const uint64_t m = __ballot(kind == k);
-            if (threadIdx.x == 0) a.chunk_count[(k - 1) * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
-            if (kind == k) a.order[(size_t)(k - 1) * a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
+        for (uint32_t k = 0; k < (uint32_t)WORK_CLASSES; ++k) {
+            const uint64_t m = __ballot(kind == 1u && cls == k);
+            if (threadIdx.x == 0) a.chunk_count[k * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
+            if (kind == 1u && cls == k) a.order[block * PREPASS_BATCHES + base + (uint32_t)__popcll(m & below)] = r;
+            base += (uint32_t)__popcll(m);
+        }
+        {   // the checked list
+            const uint64_t m = __ballot(kind == 2u);
+            if (threadIdx.x == 0) a.chunk_count[WORK_CLASSES * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
+            if (kind == 2u) a.order[(size_t)a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
         }
     }
     // LDS framebuffer windows of the batches that draw: RUNS lanes per batch, one per run of chains
@@ -940,25 +959,32 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     DrawRec rec;
     {
         const uint32_t lane = threadIdx.x & 63u, chunks = a.order_stride / PREPASS_BATCHES;
-        const uint32_t *cc = a.chunk_count + (GENERIC ? PCR_MAX_PREPASS_WORKGROUPS : 0);
-        uint32_t before = 0, found = 0xFFFFFFFFu;
-        for (uint32_t c0 = 0; c0 < chunks; c0 += 64) {                      // (uniform)
-            const uint32_t cnt = c0 + lane < chunks ? cc[c0 + lane] : 0u;
-            uint32_t incl = cnt;
+        const uint32_t classes = GENERIC ? 1u : a.work_classes;
+        uint32_t x = blockIdx.x, found = 0xFFFFFFFFu;
+        for (uint32_t cls = 0; cls < classes && found == 0xFFFFFFFFu; ++cls) {                  // (uniform; one class unless the frame has a level of detail)
+            const uint32_t *cc = a.chunk_count + (GENERIC ? WORK_CLASSES : cls) * PCR_MAX_PREPASS_WORKGROUPS;
+            uint32_t before = 0;
+            for (uint32_t c0 = 0; c0 < chunks; c0 += 64) {                  // (uniform)
+                const uint32_t cnt = c0 + lane < chunks ? cc[c0 + lane] : 0u;
+                uint32_t incl = cnt;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if ((int)lane >= d) incl += up;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d);
+                    if ((int)lane >= d) incl += up;
+                }
+                const uint32_t total = __shfl(incl, 63);
+                if (x < before + total) {
+                    const uint64_t m = __ballot(before + incl > x);        // first chunk whose inclusive count passes x
+                    const uint32_t first = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                    const uint32_t excl = __shfl(incl - cnt, first);
+                    uint32_t lighter = 0;                                   // the chunk's records of the classes in front of this one
+                    for (uint32_t k = 0; k < cls; ++k) lighter += a.chunk_count[k * PCR_MAX_PREPASS_WORKGROUPS + c0 + first];
+                    found = (c0 + first) * PREPASS_BATCHES + lighter + (x - before - excl);
+                    break;
+                }
+                before += total;
             }
-            const uint32_t total = __shfl(incl, 63);
-            if (blockIdx.x < before + total) {
-                const uint64_t m = __ballot(before + incl > blockIdx.x);   // first chunk whose inclusive count passes x
-                const uint32_t first = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-                const uint32_t excl = __shfl(incl - cnt, first);
-                found = (c0 + first) * PREPASS_BATCHES + (blockIdx.x - before - excl);
-                break;
-            }
-            before += total;
+            x -= before;                                                    // (not found: `before` is the class's total)
         }
         found = __builtin_amdgcn_readfirstlane(found);                      // (the same in every lane: keep it, and the record, scalar)
         if (found == 0xFFFFFFFFu) return;                                   // the grid is sized for "every batch visible"

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pcrhpg24_amd as P
 from pcrhpg24_amd import _native as N
-ap = argparse.ArgumentParser(); ap.add_argument("--batches", type=int, default=0); ap.add_argument("--out", default=""); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cull", type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument("--batches", type=int, default=0); ap.add_argument("--out", default=""); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cull", type=int, default=0); ap.add_argument("--lod", type=int, default=100)
 args = ap.parse_args()
 image, _ = P.synth_encode(100_000_000, 0x5EED, nthreads=16)
 hf = P.HuffmanFile(image)
@@ -16,7 +16,7 @@ for b0 in range(0, nb, 100):
     ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, nb))])
 if nb < hf.numBatches:
     ctx.upload_tail(*hf.head_words(nb))
-p = P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), args.width, args.height); p.lod_percent = 100; p.enable_frustum_culling = args.cull
+p = P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), args.width, args.height); p.lod_percent = args.lod; p.enable_frustum_culling = args.cull
 ctx.frame_begin(p)
 for _ in range(300):
     ctx.render_basic(p); ctx.frame_turn(p, p)
