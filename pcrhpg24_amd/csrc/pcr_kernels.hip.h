@@ -1390,6 +1390,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         return val;
     };
 
+#if defined(PCR_EXP_PRIO_LAST)   /* experiment: the last workgroups to start share their CU with an older one that would starve them: raise them */
+    if (blockIdx.x + PCR_EXP_PRIO_LAST >= gridDim.x) __builtin_amdgcn_s_setprio(3);
+#endif
 #if defined(PCR_EXP_PRIO_WAVE)   /* experiment: the hardware issues oldest-first; give a workgroup's later waves the higher priority */
     switch ((tid >> 8) & 3u) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -1674,7 +1677,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     // merge the window into the global framebuffer: rows of the rectangle are contiguous, so the 64 lanes of a wave
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
-#if defined(PCR_EXP_PRIO_WAVE) || defined(PCR_EXP_PRIO_SEG)
+#if defined(PCR_EXP_PRIO_WAVE) || defined(PCR_EXP_PRIO_SEG) || defined(PCR_EXP_PRIO_LAST)
     __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef PCR_EXP_TIMELINE
