@@ -2,7 +2,8 @@
 eight contiguous batch ranges (6 x 3815 + 2 x 3814 batches), of which rank 0's (followed by rank 1's head
 words, pcr_upload_tail -- the reference's pad that this stands in for: modules/compute/HuffmanLasLoader.cpp:39-41, the
 over-reading fetch huffman_mem_iter_cuda/render.cu:441-450) and the last rank's (zero pad) are drawn at 1920x1080
-(LOD 100 %, no culling) and at 4096x4096 with the frustum cull on and a camera that culls about half of the shard, by
+(LOD 100 %, no culling), at 4096x4096 with the frustum cull on and a camera that culls about half of the shard, and at
+1920x1080 with LOD 25 % + culling (all four work classes of the longest-first order), by
 both decode variants, against the oracle on the same shard; two adjacent shards merged with pcr_merge_min equal the
 oracle over their union. A shard holds more than 2048 batches, so k_render's batch search runs its second round of 64
 chunk counts and the prepass more than 64 workgroups."""
@@ -51,13 +52,19 @@ def camera_half(y_centre, w, h):
 def check_frames(ctx, of, local_first, count, y_centre):
     """1080p LOD 100 cull 0, then 4096x4096 cull 1 with about half of the shard's batches culled; both decode variants."""
     cases = (("1080p", 1920, 1080, scenes.with_flags(scenes.cameras(1920, 1080)["overview"], lod_percent=100, cull=0)),
-             ("4096 cull", 4096, 4096, scenes.with_flags(camera_half(y_centre, 4096, 4096), lod_percent=100, cull=1)))
+             ("4096 cull", 4096, 4096, scenes.with_flags(camera_half(y_centre, 4096, 4096), lod_percent=100, cull=1)),
+             # a level of detail: the drawn batches fall into all four work classes (points per chain), which k_render's search walks
+             # heaviest first, two rounds of chunk counts per class (RenderArgs::work_classes)
+             ("1080p lod 25 cull", 1920, 1080, scenes.with_flags(camera_half(y_centre, 1920, 1080), lod_percent=25, cull=1)))
     for name, w, h, p in cases:
         ctx.set_image_size(w, h)
         ofb, ost = of.render_basic(p, first=local_first, count=count, nthreads=16)
         assert ost["batches_total"] == count
         if name == "4096 cull":
             assert 0.25 * count < ost["batches_culled"] < 0.75 * count, ost
+        elif name == "1080p lod 25 cull":
+            drawn = count - ost["batches_culled"]
+            assert drawn > 0.2 * count and 0.03 * drawn * 65536 < ost["points_iterated"] < 0.9 * drawn * 65536, ost
         else:
             assert ost["points_iterated"] == count * 65536
         for variant in (P.Context.VARIANT_POINT_WINDOWS, P.Context.VARIANT_WORDS):
