@@ -484,7 +484,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r03.v98"; }
+const char *pcr_kernel_version(void) { return "r03.v100"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -1509,6 +1509,16 @@ int pcr_kernel_timing_read(pcr_ctx *c, float *avg_ms, int *launches)
     return PCR_OK;
 }
 
+#ifdef PCR_EXP_FAR_STATS
+int pcr_exp_read_far(pcr_ctx *c, unsigned long long *out, int reset)
+{
+    if (!c || !out) return PCR_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(pcr::g_far), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(pcr::g_far), z, sizeof z)); }
+    return PCR_OK;
+}
+#endif
 #ifdef PCR_EXP_TIMELINE
 int pcr_exp_read_timeline(pcr_ctx *c, unsigned long long *out, size_t n)
 {

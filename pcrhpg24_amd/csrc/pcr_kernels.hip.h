@@ -171,7 +171,9 @@ constexpr int RUN_WORDS = 4 + RUNS * 6;     // {first chain of run 1, 2, 3, 0} t
 struct WinPlan {
     uint32_t xy[RUNS], wh[RUNS];      // {x0 | y0<<16}, {w | h<<16}; w == 0: none
     uint32_t first[RUNS - 1];
-    uint32_t reserved;
+    uint32_t mostly_outside;          // 1: the windows hold less than half of the runs' rectangles -- most points of the batch will land outside
+                                      // them -- AND the same goes for most of the 32 batches around it (the prepass workgroup's vote): k_render
+                                      // then pre-reads the framebuffer word of such a point, see project_request
     uint32_t whole_xy, whole_wh;      // the screen rectangle of the batch's own bounding box, in which the prepass marked the dirty tiles
                                       // (FrameView::tiles); w == 0: it has none, or no tiles are kept
 };
@@ -315,11 +317,27 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
     }
     // LDS framebuffer windows of the batches that draw: RUNS lanes per batch, one per run of chains
     static_assert(PREPASS_BATCHES * RUNS <= PREPASS_THREADS, "one round");
+    // ... and a vote: do most of the workgroup's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
+    // k_render pre-read the framebuffer words of such a batch's points (WinPlan::mostly_outside, project_request): a few batches of
+    // that kind in a frame are cheaper unfiltered, a frame full of them (an unsorted stream) is not.
+    __shared__ uint32_t s_vote[2];                          // batches drawn, of those mostly outside
+    if (threadIdx.x < 2) s_vote[threadIdx.x] = 0;
+    __syncthreads();
+    bool mine_drawn = false;
     if (threadIdx.x < PREPASS_BATCHES * RUNS) {
         const uint32_t slot = threadIdx.x / RUNS;
         const int64_t b = (int64_t)block * PREPASS_BATCHES + slot;
-        if (b < a.s.num_batches && s_kind[slot]) plan_windows(a, b, (int)(threadIdx.x % RUNS));     // (uniform per RUNS lanes)
+        if (b < a.s.num_batches && s_kind[slot]) {
+            plan_windows(a, b, (int)(threadIdx.x % RUNS));                                           // (uniform per RUNS lanes)
+            if (threadIdx.x % RUNS == 0) {
+                mine_drawn = true;
+                atomicAdd(&s_vote[0], 1u);
+                if (a.win[b].mostly_outside) atomicAdd(&s_vote[1], 1u);     // (written by this lane a moment ago)
+            }
+        }
     }
+    __syncthreads();
+    if (mine_drawn && s_vote[1] * 2u < s_vote[0]) a.win[(int64_t)block * PREPASS_BATCHES + threadIdx.x / RUNS].mostly_outside = 0;
 }
 
 // One lane per run: the screen rectangle of the run's bounding box (k_bounds), then LDS pixels for the RUNS rectangles. Only a
@@ -356,11 +374,12 @@ __device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect whole,
         if (r == 0) rect_pack(whole, xy, wh);
         out->xy[r] = xy; out->wh[r] = wh;                                           // (runs 1..3: no window of their own)
         if (r < RUNS - 1) out->first[r] = PCR_WORKGROUP_SIZE;                       // every chain belongs to run 0
-        if (r == 0) out->reserved = 0;
+        if (r == 0) out->mostly_outside = 0;
         return;
     }
     // one window per run; while they do not fit together, the largest gives way (a run with a jump of its own inside)
     int sum = group_sum(rect_area(mine));
+    const int wanted = sum;
 #pragma unroll 1
     for (int round = 0; round < 6 && sum > cap; ++round) {
         const int area = rect_area(mine), largest = group_max(area);
@@ -374,7 +393,8 @@ __device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect whole,
     if (sum > cap) mine = none;                                                     // hopeless: this run goes the global way
     rect_pack(mine, out->xy[r], out->wh[r]);
     if (r < RUNS - 1) out->first[r] = min(runs[r], (uint32_t)PCR_WORKGROUP_SIZE);
-    if (r == 0) out->reserved = 0;
+    const int kept = group_sum(rect_area(mine));                                    // (every lane of the group: a shuffle)
+    if (r == 0) out->mostly_outside = kept * 2 < wanted ? 1u : 0u;
 }
 
 __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int r)
@@ -931,6 +951,9 @@ __device__ unsigned long long g_wave_end[8192 * 16];        // per wave: wall cl
 #define PCR_TL(slot) do { } while (0)
 #endif
 
+#ifdef PCR_EXP_FAR_STATS   /* experiment: what happens to the points outside their windows (counters per launch sequence) */
+__device__ unsigned long long g_far[8];   // wave-iterations with such lanes, lanes, pre-read iterations, -, -, waves
+#endif
 constexpr uint32_t NO_PIXEL = 0xFFFFFFFFu;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -1281,6 +1304,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     uint64_t pend_off_mask = 0;                             // lanes whose pending point is inside the frustum but outside its window
     const uint32_t whole_x0 = plan_p->whole_xy & 0xFFFFu, whole_y0 = plan_p->whole_xy >> 16;
     const uint32_t whole_w = plan_p->whole_wh & 0xFFFFu, whole_h = plan_p->whole_wh >> 16;
+    const bool mostly_outside = plan_p->mostly_outside != 0;    // (uniform) the batch and most of its neighbours lie mostly outside their windows
     uint32_t pend_pix = NO_PIXEL, pend_w = 0, pend_depth = 0;
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     lds_u64 *const s_win_mine = (lds_u64 *)(s_win + wbase); // my run's window
@@ -1595,7 +1619,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                 const uint32_t rx = (uint32_t)ix - v_wx0, ry = (uint32_t)iy - v_wy0;
                 // (bitwise: `&&` would put the two compares under a branch of their own)
                 const uint64_t in_mask = cand_mask & __builtin_amdgcn_ballot_w64(rx < ww) & __builtin_amdgcn_ballot_w64(ry < wh);
+#ifdef PCR_EXP_NO_OFFWIN   /* timing experiment only (wrong frames): what the points outside their LDS window cost */
+                pend_off_mask = 0;
+#else
                 pend_off_mask = cand_mask & ~in_mask;
+#endif
                 pend_depth = __float_as_uint(qw);                                       // :287
                 pend_p = s_win_mine + (__builtin_amdgcn_inverse_ballot_w64(in_mask) ? (uint32_t)__umul24(ry, ww) + rx : dummy_idx);
                 // (the depth half alone: the filter looks at nothing else, and a 64-bit read whose low half nobody wants had hipcc reuse
@@ -1608,6 +1636,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     // the packed-words variant then drew wrong frames (round 3; convergent operations in divergent control flow).
                     const uint64_t stray_now = g_tiles ? pend_off_mask & (__builtin_amdgcn_ballot_w64((uint32_t)ix - whole_x0 >= whole_w) |
                                                                           __builtin_amdgcn_ballot_w64((uint32_t)iy - whole_y0 >= whole_h)) : 0;
+                    const bool sample = mostly_outside;                             // (uniform) see below
+#ifdef PCR_EXP_FAR_STATS
+                    if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_far[0], 1ull); atomicAdd(&g_far[1], (unsigned long long)__builtin_popcountll(pend_off_mask)); if (sample) atomicAdd(&g_far[2], 1ull); }
+#endif
                     if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) {
                         pend_pix = (uint32_t)(ix + iy * img_w);                         // :285
                         if (__builtin_amdgcn_inverse_ballot_w64(stray_now)) {
@@ -1615,9 +1647,24 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                             const uint32_t mx = ix >= img_w ? 0u : (uint32_t)ix, my = ix >= img_w ? (uint32_t)iy + 1u : (uint32_t)iy;
                             g_tiles[(my >> TILE_H_SHIFT) * tiles_x + (mx >> TILE_W_SHIFT)] = 1;
                         }
-                        // (a relaxed atomic load: other workgroups update this word with atomics -- and, being another kind of access
-                        // than the LDS read above, it is not folded with it into one flat load of a selected pointer)
-                        pend_old_hi = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&g_fb[pend_pix]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        // The pre-read of the global framebuffer word (:297) is a filter in front of the global atomic -- min is
+                        // idempotent, the frame is the same without it -- that costs the wave a memory round trip per point. It stops
+                        // 70-85 % of the points it sees, whatever the frame (tools/exp/far_stats.py); what differs is how many there
+                        // are. In a Morton-sorted stream 0.2 % (1080p) to 5 % (close-up) of a frame's wave-iterations have such lanes,
+                        // 9-31 of them, concentrated in a few waves that the round trips turn into the launch's stragglers: without
+                        // the load 4096x4096 is 8 % faster, a close-up 7 %, the benchmark frame 2.6 %. In an unsorted stream (a batch
+                        // is a strip across the scene, ten points per pixel) it is every iteration and 57 lanes, and unfiltered the
+                        // frame takes 1.7 x the time in atomics. A few batches of that kind among the others are cheaper unfiltered (the
+                        // atomic units have room), a frame full of them is not: the prepass votes per 32 neighbouring batches
+                        // (WinPlan::mostly_outside).
+                        pend_old_hi = 0xFFFFFFFFu;
+                        if (sample) {
+                            // (consumed inside the branch: no load is pending where the paths join, so hipcc's waits for the window
+                            // rows, requested two points ahead, stay exact)
+                            uint32_t seen = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&g_fb[pend_pix]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            asm volatile("; framebuffer word of a point outside its window %0" : "+v"(seen));
+                            pend_old_hi = seen;
+                        }
                     }
                 }
                 return;
@@ -1679,6 +1726,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // hit a handful of cache lines; only pixels this batch improved issue an atomic
 #if defined(PCR_EXP_PRIO_WAVE) || defined(PCR_EXP_PRIO_SEG) || defined(PCR_EXP_PRIO_LAST)
     __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef PCR_EXP_FAR_STATS
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_far[5], 1ull);
 #endif
 #ifdef PCR_EXP_TIMELINE
     if ((threadIdx.x & 63u) == 0) g_wave_end[(size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = wall_clock64();
@@ -1892,6 +1942,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
                     const uint32_t widx = ry * ww + rx;
                     if (key < s_win[widx]) __hip_atomic_fetch_min(&s_win[widx], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (key < a.f.fb[pix]) {                              // :123-126
+                    // (kept here, unlike in k_render: strip-ordered clouds put most points outside the window, and unfiltered they
+                    // cost 8 x the time in atomics -- 0.365 -> 2.94 ms; tile-ordered 0.248 -> 0.478; only the close-up gained)
                     atomicMin((unsigned long long *)&a.f.fb[pix], key);
                 }
             }
