@@ -596,6 +596,16 @@ __device__ __forceinline__ uint32_t bc1_color(const Bc1Palette &p, uint32_t loca
     return __builtin_amdgcn_perm(p.b, rg, (sel << 16) + 0x0c040100u);                          // b[sel] << 16 | rg
 }
 
+// The same for the HQS colour pass, which wants r << 16 | g and b << 16 | 1 (the contribution of one point to the two packed sums): one
+// selector, two v_perm_b32 -- the colour itself is never put together.
+__device__ __forceinline__ void bc1_contribution(const Bc1Palette &p, uint32_t local, uint32_t &rg16, uint32_t &bc16)
+{
+    const uint32_t sel = (p.selectors >> (2 * local)) & 3u;
+    const uint32_t m = sel * 0x00010001u + 0x0c040c00u;     // byte 2 <- s0[sel], byte 0 <- s1[sel], zero elsewhere
+    rg16 = __builtin_amdgcn_perm(p.r, p.g, m);              // r[sel] << 16 | g[sel]
+    bc16 = __builtin_amdgcn_perm(p.b, 0x01010101u, m);      // b[sel] << 16 | 1
+}
+
 // BC7 mode-6 block as the reference's kernels decode it (huffman_hqs/render.cu:240-273, struct bc7_mode_6 render.cu:66-110):
 // endpoints = 7 bits << 1 | p-bit, the 4-bit field at 4 * local of the high quadword as the index of EVERY pixel (so pixel 0
 // gets index << 1 | p1: reproduced), weight = round(idx * 64 / 15) = (idx * 64 + 7) / 15, channel = (e0 (64 - w) + e1 w + 32) >> 6.
@@ -1096,8 +1106,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     }
     const uint32_t W = (uint32_t)a.p.width;
     // colour pass layout of the same bytes: sums in the framebuffer's own packed format + the depth to test against
-    unsigned long long *const s_rg = s_win, *const s_ba = s_win + win_cap;
-    uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * win_cap);
+    // (RG and BA of a pixel side by side: one address per flush of a run, the second add at offset 8; record `wpix`, behind the
+    // last window pixel, is a dummy that the first flush of a chain -- which has no run yet -- adds zeros to)
+    unsigned long long *const s_acc = s_win;
+    uint32_t *const s_depth = reinterpret_cast<uint32_t *>(s_win + 2 * (win_cap + 1));
     // every pixel of every window in turn: fn(index in the window arrays, index in the framebuffer)
     auto for_window_pixels = [&](auto fn) __attribute__((always_inline)) {
         uint32_t base = 0;
@@ -1124,8 +1136,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     } else {
         // colour pass: the depths of the rectangles as the depth pass left them, sums zeroed
         for_window_pixels([&](uint32_t i, size_t gp) {
-            s_depth[i] = (uint32_t)(a.f.fb[gp] >> 32); s_rg[i] = 0; s_ba[i] = 0;
+            s_depth[i] = (uint32_t)(a.f.fb[gp] >> 32); s_acc[2 * i] = 0; s_acc[2 * i + 1] = 0;
         });
+        if (tid == 0) { s_acc[2 * wpix] = 0; s_acc[2 * wpix + 1] = 0; }
     }
 
     // ---- my chain's own word sequence (k_transcode) ---------------------------------------------------------
@@ -1206,16 +1219,15 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // A stale `old` only makes the filter less selective: framebuffer words never increase during a pass.
     // colour pass: run of contributions to one pixel held in registers
     // (two 16-bit sums per register: a chain adds at most 64 * 255 per channel)
-    uint32_t run_pix = NO_PIXEL, run_widx = NO_PIXEL;
+    uint32_t run_pix = NO_PIXEL, run_widx = wpix;           // (no run yet: zeros for the dummy record)
     uint32_t run_rg16 = 0, run_bc16 = 0;                    // r << 16 | g,  b << 16 | count
     auto flush_run = [&]() __attribute__((always_inline)) {
-        if (run_pix == NO_PIXEL) return;
         const unsigned long long run_rg = ((unsigned long long)(run_rg16 >> 16) << 32) | (run_rg16 & 0xFFFFu);
         const unsigned long long run_ba = ((unsigned long long)(run_bc16 >> 16) << 32) | (run_bc16 & 0xFFFFu);
         if (run_widx != NO_PIXEL) {
             // per-batch partial sums in LDS (a batch adds at most 65 536 * 255 < 2^32 per 32-bit half)
-            __hip_atomic_fetch_add(&s_rg[run_widx], run_rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_ba[run_widx], run_ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_acc[2 * run_widx], run_rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_acc[2 * run_widx + 1], run_ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             atomicAdd((unsigned long long *)&g_rg[run_pix], run_rg);        // :309-310
             atomicAdd((unsigned long long *)&g_ba[run_pix], run_ba);        // :311-312
@@ -1227,9 +1239,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     // index `w` (colour pass: three planes).
     // colour pass: the contribution of a point that passed the 1 % test (hqs render.cu:297-313)
     auto accumulate = [&](bool off, uint32_t pix, uint32_t w, int point) __attribute__((always_inline)) {
-        const uint32_t rgba = BC7 ? bc7_color(pal7, (uint32_t)point & 15u) : bc1_color(pal, (uint32_t)point & 15u);
-        const uint32_t vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);   // r << 16 | g  (rgba = 0x00BBGGRR)
-        const uint32_t vbc = (rgba & 0x00FF0000u) | 1u;                        // b << 16 | 1
+        uint32_t vrg, vbc;                                                     // r << 16 | g,  b << 16 | 1
+        if (BC7) {
+            const uint32_t rgba = bc7_color(pal7, (uint32_t)point & 15u);
+            vrg = __builtin_amdgcn_perm(0u, rgba, 0x0C000C01u);                 // (rgba = 0x00BBGGRR)
+            vbc = (rgba & 0x00FF0000u) | 1u;
+        } else {
+            bc1_contribution(pal, (uint32_t)point & 15u, vrg, vbc);
+        }
         // Consecutive points of a chain are Morton neighbours and mostly land in the same pixel: their
         // contributions are summed in registers and written once per run (sums commute, so the totals
         // are unchanged; a chain adds at most 64 * 255 per 32-bit half).
@@ -1739,9 +1756,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         PCR_TL(4);
         for_window_pixels([&](uint32_t i, size_t gp) {
             if (COLOR_PASS) {
-                const unsigned long long vba = s_ba[i];
+                const unsigned long long vba = s_acc[2 * i + 1];
                 if (vba) {
-                    atomicAdd((unsigned long long *)&a.f.rg[gp], s_rg[i]);
+                    atomicAdd((unsigned long long *)&a.f.rg[gp], s_acc[2 * i]);
                     atomicAdd((unsigned long long *)&a.f.ba[gp], vba);
                 }
             } else {
