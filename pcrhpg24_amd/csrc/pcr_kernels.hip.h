@@ -237,6 +237,10 @@ __device__ __forceinline__ bool plane_accepts(float x, float y, float z, float w
 
 // Frame statistics: every prepass workgroup sums its batches in LDS and writes ONE partial record (no global atomics,
 // nothing to zero beforehand); pcr_get_stats adds the partials of the last launch. PCR_STATS_PARTIALS bounds the grid.
+#ifndef PCR_VOTE_NUM
+#define PCR_VOTE_NUM 9u      // the prepass workgroup's vote (WinPlan::mostly_outside): at least NUM / DEN of its drawn batches. (With 1 / 2 the
+#define PCR_VOTE_DEN 10u     // batches in front of a close-up camera, neighbours in the file, voted themselves in: +6 %, +20 % with culling.)
+#endif
 constexpr int PREPASS_THREADS = 256;
 constexpr int PCR_MAX_PREPASS_WORKGROUPS = 2048;        // ceil(65535 batches / 32 batches per prepass workgroup)
 constexpr int WORK_CLASSES = 4;                         // of the ordinary list, by points per chain: 49..64, 33..48, 17..32, 1..16 (RenderArgs::work_classes;
@@ -317,7 +321,7 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
     }
     // LDS framebuffer windows of the batches that draw: RUNS lanes per batch, one per run of chains
     static_assert(PREPASS_BATCHES * RUNS <= PREPASS_THREADS, "one round");
-    // ... and a vote: do most of the workgroup's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
+    // ... and a vote: do (nearly) all of the workgroup's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
     // k_render pre-read the framebuffer words of such a batch's points (WinPlan::mostly_outside, project_request): a few batches of
     // that kind in a frame are cheaper unfiltered, a frame full of them (an unsorted stream) is not.
     __shared__ uint32_t s_vote[2];                          // batches drawn, of those mostly outside
@@ -337,7 +341,7 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
         }
     }
     __syncthreads();
-    if (mine_drawn && s_vote[1] * 2u < s_vote[0]) a.win[(int64_t)block * PREPASS_BATCHES + threadIdx.x / RUNS].mostly_outside = 0;
+    if (mine_drawn && s_vote[1] * PCR_VOTE_DEN < s_vote[0] * PCR_VOTE_NUM) a.win[(int64_t)block * PREPASS_BATCHES + threadIdx.x / RUNS].mostly_outside = 0;
 }
 
 // One lane per run: the screen rectangle of the run's bounding box (k_bounds), then LDS pixels for the RUNS rectangles. Only a
