@@ -39,6 +39,12 @@ def side_path(lines):
         return "off-window scatter (global atomic)"
     if "global_load_dwordx2" in text and "v_mad_u64_u32" in text:
         return "off-window pre-read (global load)"
+    if "global_store_byte" in text:
+        return "tile of a stray point marked (dirty tiles)"
+    if "global_load_dword" in text and "offset:4" in text:
+        return "off-window pre-read (global load of the depth half; mostly_outside batches only)"
+    if "v_subrev_u32" in text and "v_cmp_le_u32" in text and "ds_" not in text:
+        return "is an off-window point a stray? (uniform branch: some lane is off its window)"
     if "v_cvt_f64_i32" in text:
         return "double-precision dequantisation (batches >= 100 px on screen)"
     return None
