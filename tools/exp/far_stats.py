@@ -1,5 +1,7 @@
 """Experiment (library built with -DPCR_EXP_FAR_STATS): the points outside their LDS windows in one frame -- how many wave-iterations have
-such lanes, how many lanes, what the sampled pre-reads filter.   PCR_HIP_LIB=tools/exp/libpcr_hip_far.so python tools/exp/far_stats.py"""
+such lanes, how many lanes, how many of those iterations pre-read the global framebuffer word (batches the prepass voted
+"mostly outside"). (The filter's pass rates quoted in profiles/r03_experiments.md section 13 came from an earlier form of this hook that
+sampled every eighth such point.)   PCR_HIP_LIB=tools/exp/libpcr_hip_far.so python tools/exp/far_stats.py"""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,9 +13,9 @@ def frame(ctx, p, label):
     out = np.zeros(8, np.uint64)
     ctx.frame_begin(p); ctx.render_basic(p); lib.pcr_exp_read_far(ctx.h, out.ctypes.data, 1)
     ctx.frame_begin(p); ctx.render_basic(p); lib.pcr_exp_read_far(ctx.h, out.ctypes.data, 1)
-    it, lanes, smp, passed, on, waves = (int(v) for v in out[:6])
-    print("%-28s wave-iterations with such lanes %9d of %9d (%.2f %%), lanes per such iteration %.1f, sampled lanes %d, passed %.1f %%, waves that switched the filter on %d of %d"
-          % (label, it, waves * 64, 100.0 * it / max(1, waves * 64), lanes / max(1, it), smp, 100.0 * passed / max(1, smp), on, waves))
+    it, lanes, pre, _, _, waves = (int(v) for v in out[:6])
+    print("%-28s wave-iterations with such lanes %9d of %9d (%.2f %%), lanes per such iteration %.1f, of those iterations pre-read (mostly_outside batches) %d"
+          % (label, it, waves * 64, 100.0 * it / max(1, waves * 64), lanes / max(1, it), pre))
 image, _ = P.synth_encode(100_000_000, 0x5EED, nthreads=16)
 hf = P.HuffmanFile(image)
 for (w, h, cam, cull, label) in ((1920, 1080, "overview", 0, "1080p overview"), (4096, 4096, "overview", 1, "4096x4096 overview"), (1920, 1080, "closeup", 0, "1080p close-up")):
