@@ -118,6 +118,24 @@ def test_batches_that_fall_apart_into_clusters_get_a_window_per_run(ctx):
                 assert ost["points_iterated"] > 0
 
 
+def test_unsorted_stream_whose_batches_are_strips_across_the_scene(ctx):
+    """`preprocess ... sort = 0`: a batch is 65 536 consecutive input points -- here rows of a height field, a strip across the whole
+    scene that no LDS window holds. Every batch of the prepass workgroup lies mostly outside its windows, so the vote sets
+    WinPlan::mostly_outside and k_render takes the one path that pre-reads the global framebuffer word of a point outside its
+    window (elsewhere such points go to the atomic unfiltered: the frame has to be the oracle's either way)."""
+    n = 700_000
+    x, y, z, c = P.synth_points(n, scenes.SEED, 0, n)
+    image, st = P.encode_points(x, y, z, c, P.synth_las_info(n, scenes.SEED), morton_sort=False, nthreads=2)
+    assert st["num_batches"] >= 10
+    of = oracle.OracleFile(image.view())
+    for w, h in ((1920, 1080), (800, 450)):
+        ctx.set_image_size(w, h)
+        load(ctx, image)
+        for cam in ("overview", "closeup"):
+            for lod, cull in ((100, 0), (40, 1)):
+                check_all(ctx, of, scenes.with_flags(scenes.cameras(w, h)[cam], lod_percent=lod, cull=cull))
+
+
 @pytest.mark.parametrize("size", [(64, 36), (33, 97), (4096, 4096)])
 def test_image_sizes_and_clipped_windows(ctx, size):
     w, h = size
