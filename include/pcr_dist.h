@@ -67,9 +67,9 @@ int pcr_dist_group_end(void);
 int pcr_dist_merge_min(pcr_dist *d, int root);          /* fb: u64 min */
 int pcr_dist_merge_sum(pcr_dist *d, int root);          /* RG and BA: u64 sum */
 
-/* Which exchange the whole-frame calls below use. AUTO (default): REDUCE while a framebuffer is smaller than
- * PCR_DIST_SLICED_MIN_BYTES or the communicator has one rank, SLICED from there on. pcr_dist_exchange: what AUTO resolves to
- * for the context's current image size (or the mode that was set). */
+/* Which exchange the whole-frame calls below use. AUTO (default) = REDUCE: the sliced forms have not met a peer on hardware yet
+ * and stay an explicit choice until they have (PCR_DIST_SLICED_MIN_BYTES: the frame size from which SLICED is expected to win, 4096x4096).
+ * pcr_dist_exchange: what AUTO resolves to (or the mode that was set). */
 #define PCR_DIST_EXCHANGE_AUTO        0
 #define PCR_DIST_EXCHANGE_REDUCE      1   /* ncclReduce / ncclAllReduce of the whole u64 frame */
 #define PCR_DIST_EXCHANGE_SLICED      2   /* ncclReduceScatter + resolve of the own slice + gather of the RGBA8 image */

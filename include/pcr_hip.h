@@ -138,9 +138,16 @@ size_t pcr_framebuffer_elems(const pcr_ctx *ctx);
  * external buffers are in use. pcr_device_rgba: the RGBA8 image the resolves write (same capacity, in pixels). */
 size_t pcr_framebuffer_capacity(const pcr_ctx *ctx);
 void *pcr_device_rgba(pcr_ctx *ctx);
+/* Raw device pointers to the context's framebuffers. CONTRACT: the library resolves and clears only the 64 x 16-pixel tiles its own
+ * kernels wrote in (dirty tiles, pcr_frame_turn). Whoever holds one of these pointers may write anywhere behind the library's back
+ * (a collective, a merge of their own), so from the first call of a getter on, EVERY frame turn and clear walks the whole frame --
+ * correct whatever is written through the pointer, 10-20 us slower per 4096x4096 frame -- until pcr_framebuffer_private(ctx) says
+ * the pointers are no longer written through. (pcr_merge_*, pcr_use_external_buffers, pcr_set_int64_mergeable and the 10-10-10
+ * method drop the tile tracking by themselves until the next full clear.) */
 void *pcr_device_framebuffer(pcr_ctx *ctx);
 void *pcr_device_rg(pcr_ctx *ctx);
 void *pcr_device_ba(pcr_ctx *ctx);
+int   pcr_framebuffer_private(pcr_ctx *ctx);
 int   pcr_use_external_buffers(pcr_ctx *ctx, void *dev_fb, void *dev_rg, void *dev_ba); /* NULLs: back to own */
 /* fb[i] = min(fb[i], other[i]) over pcr_fb_elems elements; rg/ba[i] += other[i] (NULL: skip). */
 int   pcr_merge_min(pcr_ctx *ctx, const void *dev_other_fb);
@@ -198,6 +205,13 @@ int pcr_stream_layout(const pcr_ctx *ctx);
 #define PCR_VARIANT_WORDS 1
 #define PCR_VARIANT_POINT_WINDOWS 2
 int pcr_set_render_variant(pcr_ctx *ctx, int variant);
+
+/* Workgroups per batch of the render kernels. The reference launches one 1024-thread block per batch
+ * (modules/huffman_mem_iter_cuda/render.cu:328, huffman_mem_iter_cuda.h: cuLaunchKernel grid = numBatches); this build can also
+ * draw a batch with two workgroups of 512 threads (chains 0..511 and 512..1023, four workgroups per CU) -- same frames, finer
+ * turnover of LDS and wave slots. parts: 0 = chosen by the library (default), 1 = whole batches, 2 = half-batches. Takes effect
+ * with the next prepass (pcr_frame_begin / pcr_frame_turn / a render call). */
+int pcr_set_workgroup_parts(pcr_ctx *ctx, int parts);
 /* Device bytes the loaded stream occupies right now (every per-stream allocation of the context, pads and guards included;
  * framebuffers excluded). Drops when the first frame after the last upload releases what only the load-time transcode reads. */
 int64_t pcr_stream_resident_bytes(const pcr_ctx *ctx);

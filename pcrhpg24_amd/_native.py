@@ -73,10 +73,10 @@ HIP_SYMBOLS = [
     "pcr_stream_begin", "pcr_upload_batch", "pcr_upload_batches", "pcr_upload_tail", "pcr_stream_unload", "pcr_batches_loaded",
     "pcr_points_loaded", "pcr_set_image_size", "pcr_clear", "pcr_render_basic", "pcr_render_hqs_depth",
     "pcr_render_hqs_color", "pcr_resolve_basic", "pcr_resolve_hqs", "pcr_get_stats", "pcr_read_framebuffer",
-    "pcr_read_accum", "pcr_read_rgba", "pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba",
+    "pcr_read_accum", "pcr_read_rgba", "pcr_device_framebuffer", "pcr_device_rg", "pcr_device_ba", "pcr_framebuffer_private",
     "pcr_use_external_buffers", "pcr_merge_min", "pcr_merge_sum", "pcr_flip_sign", "pcr_timing_begin",
     "pcr_timing_end", "pcr_kernel_timing_enable", "pcr_kernel_timing_read", "pcr_measure_hbm",
-    "pcr_frame_begin", "pcr_frame_turn", "pcr_set_stream_layout", "pcr_set_hbm_budget", "pcr_stream_layout", "pcr_set_render_variant", "pcr_set_int64_mergeable", "pcr_fence_record", "pcr_fence_wait", "pcr_merge_min_slices", "pcr_resolve_basic_range", "pcr_set_async_upload", "pcr_batches_resident", "pcr_last_frame_batches", "pcr_stream_algorithmic_bytes", "pcr_last_frame_algorithmic_bytes", "pcr_stream_resident_bytes", "pcr_stream_color_format", "pcr_kernel_version", "pcr_get_stream", "pcr_get_device", "pcr_framebuffer_elems", "pcr_framebuffer_capacity", "pcr_device_rgba", "pcr_resolve_hqs_range",
+    "pcr_frame_begin", "pcr_frame_turn", "pcr_set_stream_layout", "pcr_set_hbm_budget", "pcr_stream_layout", "pcr_set_render_variant", "pcr_set_workgroup_parts", "pcr_set_int64_mergeable", "pcr_fence_record", "pcr_fence_wait", "pcr_merge_min_slices", "pcr_resolve_basic_range", "pcr_set_async_upload", "pcr_batches_resident", "pcr_last_frame_batches", "pcr_stream_algorithmic_bytes", "pcr_last_frame_algorithmic_bytes", "pcr_stream_resident_bytes", "pcr_stream_color_format", "pcr_kernel_version", "pcr_get_stream", "pcr_get_device", "pcr_framebuffer_elems", "pcr_framebuffer_capacity", "pcr_device_rgba", "pcr_resolve_hqs_range",
     "pcr_las_begin", "pcr_las_upload", "pcr_las_unload", "pcr_las_batches_loaded", "pcr_render_las", "pcr_resolve_las",
     "pcr_las_algorithmic_bytes", "pcr_gpu_encode_points", "pcr_gpu_encode_free",
 ]
@@ -161,6 +161,8 @@ def hip_lib() -> C.CDLL:
         lib.pcr_stream_color_format.argtypes = [C.c_void_p]
         lib.pcr_set_stream_layout.argtypes = [C.c_void_p, C.c_int]
         lib.pcr_set_render_variant.argtypes = [C.c_void_p, C.c_int]
+        lib.pcr_set_workgroup_parts.argtypes = [C.c_void_p, C.c_int]
+        lib.pcr_framebuffer_private.argtypes = [C.c_void_p]
         lib.pcr_set_int64_mergeable.argtypes = [C.c_void_p, C.c_int]
         lib.pcr_merge_min_slices.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
         lib.pcr_resolve_basic_range.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]

@@ -18,6 +18,9 @@
 using namespace pcr;
 
 constexpr int PCR_STATS_PARTIALS = PCR_MAX_PREPASS_WORKGROUPS;   // one partial record per prepass workgroup
+#ifndef PCR_DEFAULT_PARTS
+#define PCR_DEFAULT_PARTS 2                     /* workgroups per batch of k_render unless pcr_set_workgroup_parts says otherwise */
+#endif
 constexpr int64_t TRANSCODE_CHUNK = 128;        // batches per k_transcode launch when the lane-major words are scratch (40 MB)
 
 struct pcr_ctx {
@@ -69,6 +72,7 @@ struct pcr_ctx {
     std::vector<uint32_t *> lw_segments;
     const uint32_t **d_lw_block = nullptr;      // [nB] the batch's block inside its chunk's segment
     uint32_t *d_lw_wave_row = nullptr;          // [nB * (LWC_WAVES + 1)] first row of every wave inside the block, and the end
+    uint32_t *d_lw_prov = nullptr;              // [LWC_WAVES * LW_ROWS * 64] uncompacted rows of the provisional last batch of a stream that is still loading
     uint32_t *d_wave_rows = nullptr;            // [TRANSCODE_CHUNK * LWC_WAVES] rows per wave of the chunk being transcoded (k_transcode)
     uint32_t *h_wave_rows = nullptr;            // pinned: the same on the host, then the staging of the two arrays above
     int64_t provisional_for = -1;               // batches_loaded when the provisional walk of an incomplete stream's last batch was last done
@@ -109,6 +113,8 @@ struct pcr_ctx {
     int prepass_variant_hqs = 0;
     unsigned prepass_slots = 0;                 // which of the two window plans that prepass wrote (bit 0: 8-byte pixels, bit 1: 20-byte)
     uint32_t prepass_dyn_lds = 0;
+    int prepass_parts = 0;
+    int parts_mode = 0;                         // pcr_set_workgroup_parts: 0 = chosen per frame, 1 = whole batches, 2 = half-batches
     bool big_lds_ready = false;                 // hipFuncSetAttribute done for the 140 KiB launches
     int64_t prepass_batches = 0;
     static constexpr int FENCES = 8;
@@ -139,10 +145,13 @@ struct pcr_ctx {
     int tile_cur = 0, tile_prev = 1, tile_spare = 2;    // roles of the three arrays: marked by the frame being drawn / image state / all zero
     uint32_t tile_e_cur = 1, tile_e_prev = 0, tile_epochs = 1;      // epoch that means "everything" in the cur / prev array's word
     bool tiles_tracked = false;
+    // a raw pointer to one of the context's own buffers has been handed out (pcr_device_framebuffer / _rg / _ba): whoever holds it
+    // may write anywhere at any time, so tiles are not used at all until pcr_framebuffer_private says the pointers are dead
+    bool fb_exposed = false;
 #ifdef PCR_EXP_NO_TILES     /* experiment: the whole frame is resolved and cleared, nothing marks tiles */
     bool tiles_usable() const { return false; }
 #else
-    bool tiles_usable() const { return d_tiles && fb == own_fb && rg == own_rg && ba == own_ba; }
+    bool tiles_usable() const { return d_tiles && !fb_exposed && fb == own_fb && rg == own_rg && ba == own_ba; }
 #endif
     uint8_t *tiles_half(int which) const { return d_tiles + (size_t)which * tiles_stride; }
     uint32_t *tiles_all(int which) const { return reinterpret_cast<uint32_t *>(d_tiles + 3 * (size_t)tiles_stride) + which; }
@@ -199,7 +208,7 @@ void free_stream_buffers(pcr_ctx *c)
     dfree(c->d_batches); dfree(c->d_start); dfree(c->d_encoded); dfree(c->d_separate); dfree(c->d_sep_sizes);
     dfree(c->d_table_values); dfree(c->d_table_lens); dfree(c->d_cluster_sizes); dfree(c->d_colors); dfree(c->d_colors_t); dfree(c->d_lod); dfree(c->d_win);
     for (uint32_t *seg : c->lw_segments) (void)hipFree(seg);
-    c->lw_segments.clear(); dfree(c->d_lw_block); dfree(c->d_lw_wave_row); dfree(c->d_wave_rows); c->provisional_for = -1;
+    c->lw_segments.clear(); dfree(c->d_lw_block); dfree(c->d_lw_wave_row); dfree(c->d_wave_rows); dfree(c->d_lw_prov); c->provisional_for = -1;
     dfree(c->d_lane_words); dfree(c->d_batch_flags); dfree(c->d_packed_table); dfree(c->d_point_windows); dfree(c->d_batch_runs); c->transcoded = 0;
     dfree(c->d_order); dfree(c->d_chunk_count); dfree(c->d_any_generic); c->order_stride = 0;
 
@@ -255,6 +264,15 @@ int check_params(pcr_ctx *c, const pcr_render_params *p)
     return PCR_OK;
 }
 
+// Workgroups per batch of a frame's k_render launches (RenderArgs::parts): half-batch workgroups unless told otherwise
+// (pcr_set_workgroup_parts; PCR_PARTS in the environment for experiments).
+int frame_parts(const pcr_ctx *c)
+{
+    static const char *force = getenv("PCR_PARTS");
+    if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
+    return c->parts_mode ? c->parts_mode : PCR_DEFAULT_PARTS;
+}
+
 StreamView make_stream_view(pcr_ctx *c)
 {
     StreamView s;
@@ -279,6 +297,7 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     a.f.tiles_all = c->d_tiles ? c->tiles_all(c->tile_cur) : nullptr;
     a.f.tiles_x = c->tiles_x; a.f.tiles_epoch = c->tile_e_cur; a.f.tiles_total = c->ntiles;
     a.lod = c->d_lod; a.win = c->d_win; a.win_hqs = nullptr; a.stats = c->d_stats; a.variant_hqs = variant_hqs;
+    a.parts = frame_parts(c);
     a.order = c->d_order;
     a.chunk_count = c->d_chunk_count;
     // chunks of the batches this frame draws (the prepass of the frame covered exactly these)
@@ -287,11 +306,11 @@ RenderArgs make_args(pcr_ctx *c, const pcr_render_params *p, int variant_hqs)
     return a;
 }
 
-// Does the stream hold a batch for the checked kernel? false only when the device has said so.
-bool maybe_generic_batches(pcr_ctx *c)
+// Does the stream hold a batch for the checked kernel (of workgroups of 1024 / parts threads)? false only when the device has said so.
+bool maybe_generic_batches(pcr_ctx *c, int parts)
 {
     if (c->any_generic_pending && hipEventQuery(c->any_generic_ev) == hipSuccess) c->any_generic_pending = false;
-    return c->any_generic_pending || *c->h_any_generic != 0;
+    return c->any_generic_pending || (*c->h_any_generic & bf_generic(parts)) != 0;
 }
 
 // Lane-major word sequences + packed tables (k_transcode) for every loaded batch that does not have them yet. A batch is
@@ -307,13 +326,23 @@ int enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
     if (end > c->transcoded && c->transcoded == final_end && c->provisional_for == loaded) return PCR_OK;
     if (end > c->transcoded) {
         for (int64_t b0 = c->transcoded; b0 < end; ) {
-            const int64_t n = std::min(TRANSCODE_CHUNK, end - b0);
+            // (the provisional batch is a launch of its own: with the packed-words layout its rows go to a fixed scratch block)
+            const int64_t n = b0 < final_end ? std::min(TRANSCODE_CHUNK, final_end - b0) : 1;
+            const bool provisional = b0 >= final_end;
             hipLaunchKernelGGL(k_transcode, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
                                make_stream_view(c), c->d_lane_words, c->d_batch_flags, c->d_packed_table, c->d_point_windows, c->d_colors_t,
                                c->d_any_generic, (int)b0, (int)b0, c->keep_words ? c->d_wave_rows : nullptr);
             hipLaunchKernelGGL(k_bounds, dim3((unsigned)n), dim3(PCR_WORKGROUP_SIZE), 0, st,
                                make_stream_view(c), c->d_lane_words, c->d_batch_runs, (int)b0, (int)b0);
-            if (c->keep_words) {
+            if (c->keep_words && provisional) {
+                // The last batch of a stream that is still loading, walked in front of a render call: no read-back, no allocation,
+                // no host synchronisation (a segment per provisional walk leaked ~190 KB per upload until the stream
+                // was unloaded, and the render call blocked). Its rows are copied uncompacted -- LW_ROWS per wave -- into one
+                // scratch block that every provisional walk reuses; the batch is packed into its chunk's segment once it is final.
+                hipLaunchKernelGGL(k_provisional_block, dim3(1), dim3(64), 0, st, (const uint32_t **)c->d_lw_block, c->d_lw_wave_row, c->d_lw_prov, (int)b0);
+                hipLaunchKernelGGL(k_pack_words, dim3(1), dim3(PCR_WORKGROUP_SIZE), 0, st, c->d_lane_words, (uint32_t *const *)c->d_lw_block,
+                                   c->d_lw_wave_row, (int)b0, (int)b0);
+            } else if (c->keep_words) {
                 // the compact copy: how many rows did every wave of the chunk consume? (the one place loading waits for the device)
                 uint32_t *h = c->h_wave_rows;
                 HIP_TRY(c, hipMemcpyAsync(h, c->d_wave_rows, (size_t)n * LWC_WAVES * 4, hipMemcpyDeviceToHost, st));
@@ -362,15 +391,20 @@ int enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
 uint32_t frame_dyn_lds(const pcr_ctx *c, int64_t nB)
 {
     static const char *force = getenv("PCR_EXP_DYN_LDS");              // experiments: "small" / "big"
-    if (force && force[0] == 's') return (uint32_t)DYN_LDS_BYTES;
-    if (force && force[0] == 'b') return (uint32_t)DYN_LDS_BYTES_BIG;
-    return (int64_t)c->width * c->height > nB * (int64_t)WIN_PIXELS ? (uint32_t)DYN_LDS_BYTES_BIG : (uint32_t)DYN_LDS_BYTES;
+    const bool halves = frame_parts(c) == 2;
+    const uint32_t small = halves ? (uint32_t)DYN_LDS_BYTES_HALF : (uint32_t)DYN_LDS_BYTES, big = halves ? (uint32_t)DYN_LDS_BYTES_HALF_BIG : (uint32_t)DYN_LDS_BYTES_BIG;
+    if (force && force[0] == 's') return small;
+    if (force && force[0] == 'b') return big;
+    return (int64_t)c->width * c->height > nB * (int64_t)WIN_PIXELS ? big : small;
 }
 
 template <int MODE, int LAYOUT, bool GENERIC> hipError_t allow_big_lds()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<MODE, LAYOUT, GENERIC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS_BYTES_BIG);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<MODE, LAYOUT, GENERIC, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS_BYTES_BIG);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render<MODE, LAYOUT, GENERIC, 2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS_BYTES_HALF_BIG);
+    return e;
 }
 int enable_big_lds(pcr_ctx *c)
 {
@@ -404,6 +438,7 @@ void maybe_finalize(pcr_ctx *c)
     if (*c->h_any_generic == 0) dfree_counted(c, c->d_table_values, nB * 4096);
     dfree_counted(c, c->d_lane_words, (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB) * LW_ROWS * PCR_WORKGROUP_SIZE);
     if (c->d_wave_rows) dfree_counted(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES);
+    if (c->d_lw_prov) dfree_counted(c, c->d_lw_prov, (size_t)LWC_WAVES * LW_ROWS * 64);
     c->finalized = true;
 }
 
@@ -422,16 +457,17 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
     const unsigned my_slot = color_pass ? 2u : 1u;
     const int variant_hqs = MODE != MODE_BASIC;
     const uint32_t dyn_lds = frame_dyn_lds(c, nB);
+    const int parts = frame_parts(c);
     const bool have_prepass = c->prepass_ready && c->prepass_batches == nB && c->prepass_variant_hqs == variant_hqs &&
-                              (c->prepass_slots & my_slot) && c->prepass_dyn_lds == dyn_lds &&
+                              (c->prepass_slots & my_slot) && c->prepass_dyn_lds == dyn_lds && c->prepass_parts == parts &&
                               std::memcmp(&c->prepass_params, p, sizeof *p) == 0;
     c->prepass_ready = false;
     RenderArgs a = make_args(c, p, variant_hqs);
-    WinPlan *const plan_slot[2] = { c->d_win, c->d_win + c->hdr.num_batches };
+    WinPlan *const plan_slot[2] = { c->d_win, c->d_win + c->hdr.num_batches * MAX_PARTS };
     a.win = plan_slot[color_pass ? 1 : 0];
     a.win_pixel_bytes = win_pixel_bytes;
     a.dyn_lds_bytes = dyn_lds;
-    if (dyn_lds > (uint32_t)DYN_LDS_BYTES && (rc = enable_big_lds(c))) return rc;
+    if (dyn_lds > (uint32_t)(parts == 2 ? DYN_LDS_BYTES_HALF : DYN_LDS_BYTES) && (rc = enable_big_lds(c))) return rc;
     unsigned slots = c->prepass_slots;
     if (!have_prepass) {
         // the depth pass's prepass writes the colour pass's window plan as well: cull, LOD and the batch lists are the same
@@ -446,6 +482,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
         // what the colour pass of this frame needs is in place: it runs no prepass of its own if it is given the same parameters
         c->prepass_ready = true; c->prepass_slots = 2u;
         c->prepass_params = *p; c->prepass_variant_hqs = variant_hqs; c->prepass_dyn_lds = dyn_lds; c->prepass_batches = nB;
+        c->prepass_parts = parts;
     }
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);
@@ -462,14 +499,19 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
                                           (c->variant == PCR_VARIANT_AUTO && (int64_t)c->width * c->height <= nB * (int64_t)WIN_PIXELS));
     // The grid is sized for "every batch visible"; workgroups beyond the prepass's dense list return at once. The checked
     // kernel (second list) is launched only if the stream may hold a flagged batch.
-    const bool generic = maybe_generic_batches(c);
+    const bool generic = maybe_generic_batches(c, parts);
+    // (half-batches: workgroup x draws part (x >> 3) & 1 of list entry (x >> 4) * 8 + (x & 7) -- both halves on one XCD, see k_render)
+    const dim3 grid(parts == 2 ? (unsigned)((nB + 7) / 8) * 16u : (unsigned)nB), block((unsigned)(PCR_WORKGROUP_SIZE / parts));
+#define PCR_LAUNCH(L, G) do { if (parts == 2) hipLaunchKernelGGL((k_render<MODE, L, G, 2>), grid, block, dyn_lds, c->stream, a); \
+                              else hipLaunchKernelGGL((k_render<MODE, L, G, 1>), grid, block, dyn_lds, c->stream, a); } while (0)
     if (windows) {
-        hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
-        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_POINT_WINDOWS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
+        PCR_LAUNCH(LAYOUT_POINT_WINDOWS, false);
+        if (generic) PCR_LAUNCH(LAYOUT_POINT_WINDOWS, true);
     } else {
-        hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, false>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
-        if (generic) hipLaunchKernelGGL((k_render<MODE, LAYOUT_WORDS, true>), dim3((unsigned)nB), dim3(PCR_WORKGROUP_SIZE), dyn_lds, c->stream, a);
+        PCR_LAUNCH(LAYOUT_WORDS, false);
+        if (generic) PCR_LAUNCH(LAYOUT_WORDS, true);
     }
+#undef PCR_LAUNCH
     if (timed) { HIP_TRY(c, hipEventRecord(c->kt_end[slot], c->stream)); ++c->kt_samples; }
     if (c->kt_every > 0) ++c->kt_launches;
     HIP_TRY(c, hipGetLastError());
@@ -484,7 +526,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r03.v103"; }
+const char *pcr_kernel_version(void) { return "r04.v104"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -603,15 +645,16 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (rc = dalloc_zero(c, c->d_table_lens, nB * 4096, acc)) || (rc = dalloc_zero(c, c->d_cluster_sizes, nB * 32, acc)) ||
         (rc = dalloc_zero(c, c->d_colors, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) || (rc = dalloc_zero(c, c->d_colors_t, nB * PCR_COLOR_BYTES_PER_BATCH, acc)) ||
         (rc = dalloc_zero(c, c->d_lod, nB, acc)) ||
-        (rc = dalloc_zero(c, c->d_win, 2 * nB, acc)) ||
+        (rc = dalloc_zero(c, c->d_win, 2 * MAX_PARTS * nB, acc)) ||
         (rc = dalloc_zero(c, c->d_lane_words, lw_batches * LW_ROWS * PCR_WORKGROUP_SIZE, acc)) || (rc = dalloc_zero(c, c->d_batch_flags, nB, acc)) ||
         (rc = dalloc_zero(c, c->d_packed_table, nB * PCR_HUFFMAN_TABLE_SIZE, acc)) ||
-        (rc = dalloc_zero(c, c->d_batch_runs, nB * RUN_WORDS, acc)) ||
+        (rc = dalloc_zero(c, c->d_batch_runs, nB * RUN_RECORDS * RUN_WORDS, acc)) ||
         (rc = dalloc_zero(c, c->d_order, 2 * ((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES) * PREPASS_BATCHES, acc)) ||
         (rc = dalloc_zero(c, c->d_chunk_count, (WORK_CLASSES + 1) * PCR_MAX_PREPASS_WORKGROUPS, acc)) || (rc = dalloc_zero(c, c->d_any_generic, 1, acc)) ||
         (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc))) ||
         (words && ((rc = dalloc_zero(c, c->d_lw_block, nB, acc)) || (rc = dalloc_zero(c, c->d_lw_wave_row, nB * (LWC_WAVES + 1), acc)) ||
-                   (rc = dalloc_zero(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES, acc))))) {
+                   (rc = dalloc_zero(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES, acc)) ||
+                   (rc = dalloc_zero(c, c->d_lw_prov, (size_t)LWC_WAVES * LW_ROWS * 64, acc))))) {
         free_stream_buffers(c);
         return rc;
     }
@@ -854,6 +897,14 @@ int pcr_set_hbm_budget(pcr_ctx *c, int64_t bytes)
 
 int pcr_stream_layout(const pcr_ctx *c) { return c && c->stream_open ? c->layout : -1; }
 
+int pcr_set_workgroup_parts(pcr_ctx *c, int parts)
+{
+    if (!c) return PCR_E_ARG;
+    if (parts < 0 || parts > MAX_PARTS) return set_err(c, PCR_E_ARG, "workgroups per batch: 0 (chosen per frame), 1 or 2, not %d", parts);
+    c->parts_mode = parts;
+    return PCR_OK;
+}
+
 int pcr_set_render_variant(pcr_ctx *c, int variant)
 {
     if (!c) return PCR_E_ARG;
@@ -1015,7 +1066,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     const TileFlags tflags = tiles_at_clear(c);
     RenderArgs a = make_args(c, p, method != PCR_METHOD_BASIC);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;         // first pass of either method (basic / HQS depth)
-    if (method == PCR_METHOD_HQS) a.win_hqs = c->d_win + c->hdr.num_batches;     // ... and the colour pass's plan with it
+    if (method == PCR_METHOD_HQS) a.win_hqs = c->d_win + c->hdr.num_batches * MAX_PARTS;     // ... and the colour pass's plan with it
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
@@ -1024,7 +1075,7 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     c->accum_dirty = false;
     c->prepass_ready = true;
     c->prepass_params = *p; c->prepass_variant_hqs = a.variant_hqs; c->prepass_slots = a.win_hqs ? 3u : 1u;
-    c->prepass_dyn_lds = a.dyn_lds_bytes;
+    c->prepass_dyn_lds = a.dyn_lds_bytes; c->prepass_parts = a.parts;
     c->prepass_batches = nB;
     return PCR_OK;
 }
@@ -1058,7 +1109,7 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
     maybe_finalize(c);
     RenderArgs a = make_args(c, p_next, hqs);
     a.win_pixel_bytes = WIN_PIXEL_BYTES;
-    if (hqs) a.win_hqs = c->d_win + c->hdr.num_batches;
+    if (hqs) a.win_hqs = c->d_win + c->hdr.num_batches * MAX_PARTS;
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
     const uint32_t pixels = (uint32_t)((size_t)c->width * c->height);
@@ -1093,7 +1144,7 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
     c->accum_dirty = false;
     c->prepass_ready = true;
     c->prepass_params = *p_next; c->prepass_variant_hqs = a.variant_hqs; c->prepass_slots = a.win_hqs ? 3u : 1u;
-    c->prepass_dyn_lds = a.dyn_lds_bytes;
+    c->prepass_dyn_lds = a.dyn_lds_bytes; c->prepass_parts = a.parts;
     c->prepass_batches = nB;
     return PCR_OK;
 }
@@ -1102,6 +1153,7 @@ int pcr_set_int64_mergeable(pcr_ctx *c, int on)
 {
     if (!c) return PCR_E_ARG;
     c->empty_key = on ? 0x7FFFFFFFFFFFFFFFull : ~0ull;
+    c->tiles_tracked = false;       // a tile turn rewrites the empty word in the dirty tiles only: the next clear has to be a full one
     return PCR_OK;
 }
 
@@ -1318,9 +1370,16 @@ size_t pcr_framebuffer_capacity(const pcr_ctx *c)
 }
 void *pcr_device_rgba(pcr_ctx *c) { return c ? c->d_rgba : nullptr; }
 // (whoever asks for these may write through them -- a collective merging partial frames in place: no tile flags until the next clear)
-void *pcr_device_framebuffer(pcr_ctx *c) { if (c) c->tiles_tracked = false; return c ? c->fb : nullptr; }
-void *pcr_device_rg(pcr_ctx *c) { if (c) c->tiles_tracked = false; return c ? c->rg : nullptr; }
-void *pcr_device_ba(pcr_ctx *c) { if (c) c->tiles_tracked = false; return c ? c->ba : nullptr; }
+static void expose(pcr_ctx *c) { if (c) { c->tiles_tracked = false; c->fb_exposed = true; } }
+void *pcr_device_framebuffer(pcr_ctx *c) { expose(c); return c ? c->fb : nullptr; }
+void *pcr_device_rg(pcr_ctx *c) { expose(c); return c ? c->rg : nullptr; }
+void *pcr_device_ba(pcr_ctx *c) { expose(c); return c ? c->ba : nullptr; }
+int pcr_framebuffer_private(pcr_ctx *c)
+{
+    if (!c) return PCR_E_ARG;
+    c->fb_exposed = false; c->tiles_tracked = false;        // (tracking resumes with the next full clear)
+    return PCR_OK;
+}
 
 int pcr_use_external_buffers(pcr_ctx *c, void *fb, void *rg, void *ba)
 {

@@ -172,8 +172,11 @@ int pcr_dist_exchange(const pcr_dist *d)
 {
     if (!d) return PCR_DIST_EXCHANGE_REDUCE;
     if (d->exchange != PCR_DIST_EXCHANGE_AUTO) return d->exchange;
-    return d->world > 1 && pcr_framebuffer_elems(d->ctx) * 8 >= (size_t)PCR_DIST_SLICED_MIN_BYTES ? PCR_DIST_EXCHANGE_SLICED
-                                                                                                  : PCR_DIST_EXCHANGE_REDUCE;
+    // AUTO is REDUCE, whatever the frame's size: the sliced exchange (in-place reduce-scatter over the padded frame, gather with
+    // sendbuff == recvbuff + rank * count, the all-to-all into scratch) has only ever run on a one-rank communicator, where every
+    // collective is a self-copy (no box with peers yet: SCALE_r01..r03 skipped). It stays an explicit choice
+    // (pcr_dist_set_exchange / --merge sliced) until tests/test_dist_native.py's >= 2-GPU branch has passed on hardware.
+    return PCR_DIST_EXCHANGE_REDUCE;
 }
 
 void pcr_dist_slice_range(size_t elems, int world, int rank, size_t *first, size_t *count)

@@ -46,8 +46,19 @@ constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                 
 constexpr int DYN_LDS_BYTES  = 60 * 1024;
 constexpr int DYN_LDS_BYTES_BIG = 140 * 1024;
 constexpr int ESC_POOL_WORDS = 13312;            // most escape words of a batch the pool ever holds -> 52 KiB
-constexpr int ESC_POOL_EAGER = 7168;             // words every workgroup requests before it knows the batch's count
 constexpr int ESC_SLACK      = 64;               // words behind the batch's own escapes kept in the pool as well
+// HALF-BATCH WORKGROUPS (round 4; k_render<..., PARTS = 2>): a workgroup of 512 threads draws chains [512 part, 512 part + 512) of
+// a batch, four such workgroups per CU: 16 KiB table + 24 KiB of dynamic LDS each (the part's own escape words + windows for the
+// part's rectangle, about half the batch's). Same eight waves per SIMD; what changes is the granularity at which LDS and wave
+// slots turn over: a workgroup's waves leave their point loop up to 12 us apart (oldest-first arbiter), its LDS is held from
+// set-up to merge, and a launch of 1526 whole batches is three lock-step generations. Departs from render.cu:328 (one block per
+// batch) and :383-395 (the table staged once per block: here twice, the second read from L2 -- the two halves of a batch are
+// mapped to the same XCD, see k_render).
+constexpr int DYN_LDS_BYTES_HALF     = 24 * 1024;    // four workgroups per CU (4 x (16 + 24) KiB = 160 KiB)
+constexpr int DYN_LDS_BYTES_HALF_BIG = 62 * 1024;    // two per CU: large images (the 140 KiB configuration's counterpart)
+constexpr int ESC_POOL_WORDS_HALF    = 5120;         // most escape words of a half-batch its pool ever holds -> 20 KiB
+constexpr int MAX_PARTS = 2;
+__host__ __device__ constexpr int esc_pool_max(int parts) { return parts == 1 ? ESC_POOL_WORDS : ESC_POOL_WORDS_HALF; }
 constexpr int WIN_PIXELS     = 4096;             // nominal window (a batch with 7104 escape words); the 10-10-10 kernel's fixed one
 constexpr int WIN_PIXEL_BYTES     = 8;           // basic / HQS depth: the u64 framebuffer word
 constexpr int WIN_PIXEL_BYTES_HQS = 20;          // HQS colour: {RG u64, BA u64, depth u32}
@@ -57,16 +68,17 @@ constexpr int WIN_PIXELS_MAX = DYN_LDS_BYTES / WIN_PIXEL_BYTES;         // of th
 // (BF_GENERIC_SLOW_PATH) and its chains check every escape index: the first ESC_POOL_WORDS still come from LDS, only
 // the rest from global memory. (Pooling none of an oversized batch's escapes made that batch twice as slow, and a few
 // such batches made the whole launch 14 % longer: they finish last on their CUs.)
-__device__ __forceinline__ uint32_t esc_pool_words(uint32_t esc_total)
+// (`esc_count`: the escape words of the workgroup's own chains -- the whole batch's, or one part's)
+__device__ __forceinline__ uint32_t esc_pool_words(uint32_t esc_count, int parts = 1)
 {
-    return min(esc_total + (uint32_t)ESC_SLACK, (uint32_t)ESC_POOL_WORDS);
+    return min(esc_count + (uint32_t)ESC_SLACK, (uint32_t)esc_pool_max(parts));
 }
 __device__ __forceinline__ uint32_t esc_pool_bytes(uint32_t pool_words) { return (pool_words * 4u + 15u) & ~15u; }
 // pixels the batch's LDS window can hold next to its escape pool
-__device__ __forceinline__ int window_capacity(uint32_t esc_total, int pixel_bytes, uint32_t dyn_lds_bytes)
+__device__ __forceinline__ int window_capacity(uint32_t esc_count, int pixel_bytes, uint32_t dyn_lds_bytes, int parts = 1)
 {
     // (one pixel less than fits: the slot behind the last window pixel is k_render's dummy slot, see there)
-    return (int)((dyn_lds_bytes - esc_pool_bytes(esc_pool_words(esc_total))) / (uint32_t)pixel_bytes) - 1;
+    return (int)((dyn_lds_bytes - esc_pool_bytes(esc_pool_words(esc_count, parts))) / (uint32_t)pixel_bytes) - 1;
 }
 
 // Lane-major copy of the word stream (k_transcode): row r holds the r-th word each of the batch's 1024 chains consumes.
@@ -95,7 +107,9 @@ constexpr uint32_t PW_GUARD_BYTES = 2 * PW_HI_ROW_BYTES;
 enum { LAYOUT_WORDS = 0, LAYOUT_POINT_WINDOWS = 1 };
 // batch_flags: set when some chain of the batch can meet an in-table value outside the packed entry's range or read an
 // escape word outside k_render's LDS pool (k_transcode walks all 192 symbols of every chain, garbage tails included)
-constexpr uint32_t BF_GENERIC_SLOW_PATH = 1u;
+constexpr uint32_t BF_GENERIC_SLOW_PATH = 1u;      // ... of a whole-batch workgroup (PARTS == 1)
+constexpr uint32_t BF_GENERIC_SLOW_PATH_HALF = 2u; // ... of a half-batch workgroup (PARTS == 2: its pool holds its own part's escapes only)
+__host__ __device__ constexpr uint32_t bf_generic(int parts) { return parts == 1 ? BF_GENERIC_SLOW_PATH : BF_GENERIC_SLOW_PATH_HALF; }
 // packed table entry: byte 0 = len, bits 31:10 = the value as a signed 22-bit number -- (int32)entry >> 10 is the delta, no
 // bias to remove -- except that the most negative one, TE_SLOW_VALUE, is reserved: "the value is not in the entry" (an escape,
 // bit 8, or an in-table value outside (-2^21, 2^21), bit 9). Cost model behind the layout (tools/exp/instr_rate2.hip, gfx950):
@@ -128,14 +142,15 @@ struct StreamView {
     const uint32_t *batch_flags;      // [nB] BF_* bits written by k_transcode
     const uint32_t *packed_table;     // [nB*4096] k_render's table entries, packed by k_transcode
     const uint8_t  *point_windows;    // [nB * PW_BATCH_BYTES + PW_GUARD_BYTES] or NULL (layout), written by k_transcode
-    const uint32_t *batch_runs;       // [nB * RUN_WORDS] k_bounds: where a batch's chains fall apart into spatial clusters (see BatchRuns)
+    const uint32_t *batch_runs;       // [nB * RUN_RECORDS * RUN_WORDS] k_bounds: where a batch's (a half-batch's) chains fall apart into spatial clusters
     int64_t encoded_words;
     int64_t separate_words;
     int64_t num_batches;
     int64_t batch_index_base;
 };
 
-struct DrawRec { uint32_t b, lod, esc_total, reserved; int64_t sep_off; int64_t reserved2; };     // 32 bytes
+// (esc_mid: the escape words of chains 0..511 -- where a half-batch workgroup's share of the batch's escapes begins / ends)
+struct DrawRec { uint32_t b, lod, esc_total, esc_mid; int64_t sep_off; int64_t reserved2; };     // 32 bytes
 
 struct FrameView {
     uint64_t *fb;
@@ -164,7 +179,11 @@ constexpr uint32_t TILE_W_SHIFT = 6, TILE_H_SHIFT = 4;     // 64 x 16 pixels: a 
 // (4096x4096: a fifth of the batches, 38 %). So, once per loaded batch (k_bounds, camera independent): the three largest gaps
 // between consecutive chains cut the batch into RUNS runs of chains, each with its own bounding box.
 constexpr int RUNS = 4;
-constexpr int RUN_WORDS = 4 + RUNS * 6;     // {first chain of run 1, 2, 3, 0} then per run {min xyz, max xyz} as floats
+// One record per workgroup shape and part -- record 0: the whole batch, records 1 and 2: its halves (chains 0..511, 512..1023), each
+// cut at ITS three largest jumps:
+constexpr int RUN_WORDS = 4 + RUNS * 6 + 6; // {first chain of run 1, 2, 3, 0}, per run {min xyz, max xyz} as floats, then the box of ALL the part's chains
+constexpr int RUN_RECORDS = 1 + MAX_PARTS;  // per batch
+__host__ __device__ constexpr int run_record(int parts, int part) { return parts == 1 ? 0 : 1 + part; }
 // Per frame (prepass, a placement hint: any plan gives the same frame): one LDS framebuffer window per run, or one for the
 // whole batch when the runs' rectangles overlap anyway. first[r] = first chain of run r + 1 (1024: no such run); window r
 // sits behind windows 0 .. r-1 in the array of window pixels.
@@ -183,7 +202,7 @@ struct RenderArgs {
     StreamView s;
     FrameView f;
     uint32_t *lod;            // [nB]
-    WinPlan *win;             // [nB] LDS framebuffer windows per batch, for pixels of win_pixel_bytes
+    WinPlan *win;             // [nB * parts] LDS framebuffer windows per workgroup, for pixels of win_pixel_bytes
     WinPlan *win_hqs;         // prepass only: if not NULL, a second plan for the 20-byte pixels of the HQS colour pass is written here
                               // (the depth pass's prepass serves the colour pass of the same frame: one prepass per frame)
     pcr_render_stats *stats;  // device: one partial record per prepass workgroup
@@ -212,6 +231,8 @@ struct RenderArgs {
     // workgroup that finishes last moves the records into one dense array, so that workgroup x starts from ONE load -- was built
     // and measured: k_render -2 %, but 9 us more on the critical path of the launch that carries the prepass. Dropped.)
     int variant_hqs;          // LOD expression variant
+    int parts;                // workgroups per batch of the following k_render launches (1: 1024 threads, 2: half-batches of 512): `win` /
+                              // `win_hqs` then hold `parts` plans per batch ([b * parts + part]), the lists' "checked" class follows bf_generic(parts)
     int win_pixel_bytes;      // what a window pixel of the following k_render<MODE> takes in LDS (WIN_PIXEL_BYTES*)
     uint32_t dyn_lds_bytes;   // dynamic LDS of the following k_render launch: DYN_LDS_BYTES or DYN_LDS_BYTES_BIG
 };
@@ -271,7 +292,7 @@ __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_r
 constexpr int PREPASS_LANES = 8;
 constexpr int PREPASS_BATCHES = PREPASS_THREADS / PREPASS_LANES;     // batches per workgroup
 __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
-__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int j);
+__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int part, int j);
 
 __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t block)
 {
@@ -286,7 +307,7 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
         if (lane == 0) {
             const uint32_t lod = a.lod[b];
             if (!(lod & LOD_CULLED) && (lod & LOD_NPR_MASK))
-                s_kind[threadIdx.x / PREPASS_LANES] = (a.s.batch_flags[b] & BF_GENERIC_SLOW_PATH) ? 2u : 1u;
+                s_kind[threadIdx.x / PREPASS_LANES] = (a.s.batch_flags[b] & bf_generic(a.parts)) ? 2u : 1u;
         }
     }
     commit_stats(st, a.stats);                              // (barriers inside: s_kind is complete afterwards)
@@ -300,6 +321,7 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
             const uint32_t bb = block * PREPASS_BATCHES + threadIdx.x;
             r.b = bb; r.lod = a.lod[bb];
             r.esc_total = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 1023];
+            r.esc_mid = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 511];
             r.sep_off = a.s.batches[bb].separate_batch_offset;
         }
         // the ordinary list: class after class inside the chunk
@@ -319,29 +341,30 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
             if (kind == 2u) a.order[(size_t)a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
         }
     }
-    // LDS framebuffer windows of the batches that draw: RUNS lanes per batch, one per run of chains
-    static_assert(PREPASS_BATCHES * RUNS <= PREPASS_THREADS, "one round");
+    // LDS framebuffer windows of the workgroups that draw: RUNS lanes per batch and part, one per run of chains
+    static_assert(PREPASS_BATCHES * RUNS * MAX_PARTS <= PREPASS_THREADS, "one round");
     // ... and a vote: do (nearly) all of the workgroup's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
     // k_render pre-read the framebuffer words of such a batch's points (WinPlan::mostly_outside, project_request): a few batches of
     // that kind in a frame are cheaper unfiltered, a frame full of them (an unsorted stream) is not.
-    __shared__ uint32_t s_vote[2];                          // batches drawn, of those mostly outside
+    __shared__ uint32_t s_vote[2];                          // plans drawn, of those mostly outside
     if (threadIdx.x < 2) s_vote[threadIdx.x] = 0;
     __syncthreads();
     bool mine_drawn = false;
-    if (threadIdx.x < PREPASS_BATCHES * RUNS) {
-        const uint32_t slot = threadIdx.x / RUNS;
-        const int64_t b = (int64_t)block * PREPASS_BATCHES + slot;
-        if (b < a.s.num_batches && s_kind[slot]) {
-            plan_windows(a, b, (int)(threadIdx.x % RUNS));                                           // (uniform per RUNS lanes)
+    const uint32_t parts = (uint32_t)a.parts, plan_lanes = RUNS * parts;
+    const uint32_t slot = threadIdx.x / plan_lanes, part = (threadIdx.x / RUNS) % parts;
+    const int64_t pb = (int64_t)block * PREPASS_BATCHES + slot;
+    if (threadIdx.x < PREPASS_BATCHES * plan_lanes) {
+        if (pb < a.s.num_batches && s_kind[slot]) {
+            plan_windows(a, pb, (int)part, (int)(threadIdx.x % RUNS));                                   // (uniform per RUNS lanes)
             if (threadIdx.x % RUNS == 0) {
                 mine_drawn = true;
                 atomicAdd(&s_vote[0], 1u);
-                if (a.win[b].mostly_outside) atomicAdd(&s_vote[1], 1u);     // (written by this lane a moment ago)
+                if (a.win[pb * parts + part].mostly_outside) atomicAdd(&s_vote[1], 1u);     // (written by this lane a moment ago)
             }
         }
     }
     __syncthreads();
-    if (mine_drawn && s_vote[1] * PCR_VOTE_DEN < s_vote[0] * PCR_VOTE_NUM) a.win[(int64_t)block * PREPASS_BATCHES + threadIdx.x / RUNS].mostly_outside = 0;
+    if (mine_drawn && s_vote[1] * PCR_VOTE_DEN < s_vote[0] * PCR_VOTE_NUM) a.win[pb * parts + part].mostly_outside = 0;
 }
 
 // One lane per run: the screen rectangle of the run's bounding box (k_bounds), then LDS pixels for the RUNS rectangles. Only a
@@ -365,17 +388,18 @@ __device__ __forceinline__ void rect_pack(IRect r, uint32_t &xy, uint32_t &wh)
     wh = (uint32_t)(r.x1 - r.x0 + 1) | ((uint32_t)(r.y1 - r.y0 + 1) << 16);
 }
 
-// Windows for one pixel size, given the run's rectangle `mine` and the batch's own rectangle `whole` (uniform work per RUNS lanes).
-__device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect whole, const uint32_t *runs, int r, WinPlan *out)
+// Windows for one pixel size, given the run's rectangle `mine` and the rectangle `single` that holds every chain of the workgroup
+// (uniform work per RUNS lanes).
+__device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect single, const uint32_t *runs, int r, WinPlan *out)
 {
     auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
     auto group_max = [](int v) { v = max(v, __shfl_xor(v, 1, RUNS)); v = max(v, __shfl_xor(v, 2, RUNS)); return v; };
     const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };
-    // The rectangle of the batch's own bounding box (GPUBatch: it holds every point, the runs' boxes leave the straddling chains
-    // out): if the LDS holds it, it is the one window of the batch and no point lands outside.
-    if (rect_area(whole) > 0 && rect_area(whole) <= cap) {
+    // The rectangle of all the workgroup's chains (the batch's own bounding box, GPUBatch, cut down to what k_bounds saw of the
+    // part; the runs' boxes leave the straddling chains out): if the LDS holds it, it is the one window and no point lands outside.
+    if (rect_area(single) > 0 && rect_area(single) <= cap) {
         uint32_t xy = 0, wh = 0;
-        if (r == 0) rect_pack(whole, xy, wh);
+        if (r == 0) rect_pack(single, xy, wh);
         out->xy[r] = xy; out->wh[r] = wh;                                           // (runs 1..3: no window of their own)
         if (r < RUNS - 1) out->first[r] = PCR_WORKGROUP_SIZE;                       // every chain belongs to run 0
         if (r == 0) out->mostly_outside = 0;
@@ -401,12 +425,54 @@ __device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect whole,
     if (r == 0) out->mostly_outside = kept * 2 < wanted ? 1u : 0u;
 }
 
-__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int r)
+// The screen rectangle of a box, worked out by a group of RUNS lanes (corners 2 r and 2 r + 1 per lane, then the union over the
+// group); no rectangle for a box that reaches behind the camera, holds a NaN, or lies off screen.
+__device__ __forceinline__ IRect group_box_rect(const pcr_render_params &p, const float *bmin, const float *bmax, int r)
+{
+    const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };
+    const float fw = (float)p.width, fh = (float)p.height;
+    auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
+    bool front = true;
+    float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
+#pragma unroll
+    for (int c2 = 0; c2 < 8 / RUNS; ++c2) {
+        const int c = r * (8 / RUNS) + c2;
+        const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
+        const float w = dot4(p.transform + 12, x, y, z, 1.0f);
+        front = front && w > 1.0e-6f;
+        const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
+        const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+#pragma unroll
+    for (int m = 1; m < RUNS; m <<= 1) {
+        minx = fminf(minx, __shfl_xor(minx, m, RUNS)); maxx = fmaxf(maxx, __shfl_xor(maxx, m, RUNS));
+        miny = fminf(miny, __shfl_xor(miny, m, RUNS)); maxy = fmaxf(maxy, __shfl_xor(maxy, m, RUNS));
+    }
+    const bool all_front = (group_sum(front ? 1 : 0) == RUNS);
+    IRect rc = none;
+    if (all_front && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
+        rc.x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1); rc.x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
+        rc.y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1); rc.y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
+        if (rc.x1 < rc.x0 || rc.y1 < rc.y0) rc = none;
+    }
+    return rc;
+}
+__device__ __forceinline__ IRect rect_intersect(IRect a, IRect b)
+{
+    const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };
+    const IRect c = { max(a.x0, b.x0), max(a.y0, b.y0), min(a.x1, b.x1), min(a.y1, b.y1) };
+    return c.x1 >= c.x0 && c.y1 >= c.y0 ? c : none;
+}
+
+__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int part, int r)
 {
     const pcr_render_params &p = a.p;
     const float fw = (float)p.width, fh = (float)p.height;
-    const uint32_t esc_total = (uint32_t)a.s.separate_sizes[(size_t)b * 1024 + 1023];
-    const uint32_t *runs = a.s.batch_runs + (size_t)b * RUN_WORDS;
+    const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
+    // the escape words of the workgroup's own chains (its pool, and what is left of the LDS for its windows)
+    const uint32_t esc_count = a.parts == 1 ? (uint32_t)ssz[1023] : part == 0 ? (uint32_t)ssz[511] : (uint32_t)(ssz[1023] - ssz[511]);
+    const uint32_t *runs = a.s.batch_runs + ((size_t)b * RUN_RECORDS + run_record(a.parts, part)) * RUN_WORDS;
     const float *box = reinterpret_cast<const float *>(runs + 4 + r * 6);
     const float bmin[3] = { box[0], box[1], box[2] }, bmax[3] = { box[3], box[4], box[5] };
     const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };      // identity of the union
@@ -430,39 +496,33 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
             if (mine.x1 < mine.x0 || mine.y1 < mine.y0) mine = none;
         }
     }
-    auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
-    IRect whole = none;
+    // the batch's own bounding box (GPUBatch: it holds every point but the garbage tails of SURVEY B.4): the dirty tiles are marked under it
+    IRect whole;
     {
         const pcr_gpu_batch *g = a.s.batches + b;
         const float lm[3] = { (float)g->las_min_x, (float)g->las_min_y, (float)g->las_min_z };
         const float gmin[3] = { g->min_x - lm[0], g->min_y - lm[1], g->min_z - lm[2] }, gmax[3] = { g->max_x - lm[0], g->max_y - lm[1], g->max_z - lm[2] };
-        // corners 2 r and 2 r + 1 per lane, then the union over the group
-        bool front = true;
-        float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
-#pragma unroll
-        for (int c2 = 0; c2 < 8 / RUNS; ++c2) {
-            const int c = r * (8 / RUNS) + c2;
-            const float x = (c & 1) ? gmax[0] : gmin[0], y = (c & 2) ? gmax[1] : gmin[1], z = (c & 4) ? gmax[2] : gmin[2];
-            const float w = dot4(p.transform + 12, x, y, z, 1.0f);
-            front = front && w > 1.0e-6f;
-            const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
-            const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
-            minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
-        }
-#pragma unroll
-        for (int m = 1; m < RUNS; m <<= 1) {
-            minx = fminf(minx, __shfl_xor(minx, m, RUNS)); maxx = fmaxf(maxx, __shfl_xor(maxx, m, RUNS));
-            miny = fminf(miny, __shfl_xor(miny, m, RUNS)); maxy = fmaxf(maxy, __shfl_xor(maxy, m, RUNS));
-        }
-        const bool all_front = (group_sum(front ? 1 : 0) == RUNS);
-        if (all_front && maxx >= -1.0f && maxy >= -1.0f && minx <= fw + 1.0f && miny <= fh + 1.0f) {
-            whole.x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1); whole.x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
-            whole.y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1); whole.y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
-        }
+        whole = group_box_rect(p, gmin, gmax, r);
     }
-    assign_windows(window_capacity(esc_total, a.win_pixel_bytes, a.dyn_lds_bytes), mine, whole, runs, r, a.win + b);
+    // ... and what k_bounds saw of the workgroup's own chains, garbage tails included (a hint: float dequantisation): the one
+    // window of the workgroup if the LDS holds it
+    IRect single;
+    {
+        const float *ab = reinterpret_cast<const float *>(runs + 4 + RUNS * 6);
+        const float amin[3] = { ab[0], ab[1], ab[2] }, amax[3] = { ab[3], ab[4], ab[5] };
+        single = group_box_rect(p, amin, amax, r);
+    }
+    if (rect_area(whole) > 0) {
+        // No window reaches outside the rectangle the dirty tiles are marked under (FrameView::tiles): a point INSIDE its window is
+        // never tested against that rectangle, so a window sticking out of it -- a run's box holds its chains' garbage tails -- would
+        // let the merge write framebuffer words in a tile nobody marked. What lies outside goes the off-window way,
+        // which marks.
+        single = rect_area(single) > 0 ? rect_intersect(single, whole) : whole;
+        mine = rect_intersect(mine, whole);
+    }
+    assign_windows(window_capacity(esc_count, a.win_pixel_bytes, a.dyn_lds_bytes, a.parts), mine, single, runs, r, a.win + b * a.parts + part);
     if (a.win_hqs)                                              // (uniform) the colour pass of the same frame: 20-byte pixels
-        assign_windows(window_capacity(esc_total, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes), mine, whole, runs, r, a.win_hqs + b);
+        assign_windows(window_capacity(esc_count, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes, a.parts), mine, single, runs, r, a.win_hqs + b * a.parts + part);
     // dirty tiles (FrameView::tiles): everything under the batch's rectangle; a batch without one can write anywhere
     uint32_t wxy = 0, wwh = 0;
     if (a.f.tiles) {
@@ -472,8 +532,8 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
             const uint32_t ntx = ((uint32_t)whole.x1 >> TILE_W_SHIFT) - tx0 + 1u, nty = ((uint32_t)whole.y1 >> TILE_H_SHIFT) - ty0 + 1u;
             if (ntx * nty * 4u > a.f.tiles_total) {
                 // a batch that close to the camera covers a quarter of the screen or more: "everything", and the turn walks the frame linearly
-                if (r == 0) *a.f.tiles_all = a.f.tiles_epoch;
-            } else {
+                if (r == 0 && part == 0) *a.f.tiles_all = a.f.tiles_epoch;
+            } else if (part == 0) {                                                     // (the batch's first group of lanes marks)
                 for (uint32_t ty = (uint32_t)r; ty < nty; ty += RUNS) {                  // a row of tiles per lane and turn
                     uint8_t *row = a.f.tiles + (ty0 + ty) * a.f.tiles_x + tx0, *end = row + ntx;
                     while (row < end && ((uintptr_t)row & 3u)) *row++ = 1;
@@ -481,13 +541,14 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
                     while (row < end) *row++ = 1;
                 }
             }
-        } else if (r == 0) {
+        } else if (r == 0 && part == 0) {
             *a.f.tiles_all = a.f.tiles_epoch;
         }
     }
     if (r == 0) {
-        a.win[b].whole_xy = wxy; a.win[b].whole_wh = wwh;
-        if (a.win_hqs) { a.win_hqs[b].whole_xy = wxy; a.win_hqs[b].whole_wh = wwh; }
+        WinPlan *w = a.win + b * a.parts + part;
+        w->whole_xy = wxy; w->whole_wh = wwh;
+        if (a.win_hqs) { w = a.win_hqs + b * a.parts + part; w->whole_xy = wxy; w->whole_wh = wwh; }
     }
 }
 
@@ -770,16 +831,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_transcode(StreamView s, 
         for (int m = 1; m < 64; m <<= 1) rows = max(rows, (uint32_t)__shfl_xor((int)rows, m));
         if ((tid & 63u) == 0) wave_rows[(size_t)(b - (uint32_t)lane_words_first) * LWC_WAVES + (tid >> 6)] = rows;
     }
-    // may k_render read this batch's escapes from its LDS pool unchecked? (same pool rule as there)
+    // may k_render read this batch's escapes from its LDS pool unchecked? (same pool rules as there: the whole batch's escapes in
+    // the pool of a 1024-thread workgroup, a half's in the pool of a half-batch workgroup)
     const int32_t *ssz = s.separate_sizes + (size_t)b * 1024;
-    const uint32_t esc_total = (uint32_t)ssz[1023];
-    const uint32_t esc_lds = esc_pool_words(esc_total);
+    const uint32_t esc_total = (uint32_t)ssz[1023], esc_mid = (uint32_t)ssz[511];
     const uint32_t sp0 = tid ? (uint32_t)ssz[tid - 1] : 0u;
-    if (nesc && sp0 + nesc > esc_lds) generic = true;
-    const int any = __syncthreads_or(generic ? 1 : 0);
+    const bool over1 = nesc && sp0 + nesc > esc_pool_words(esc_total, 1);
+    const uint32_t e0 = tid < 512u ? 0u : esc_mid, e1 = tid < 512u ? esc_mid : esc_total;
+    const bool over2 = nesc && (sp0 - e0) + nesc > esc_pool_words(e1 - e0, 2);
+    const int any1 = __syncthreads_or(generic || over1 ? 1 : 0), any2 = __syncthreads_or(generic || over2 ? 1 : 0);
     if (tid == 0) {
-        batch_flags[b] = any ? BF_GENERIC_SLOW_PATH : 0u;
-        if (any) atomicOr(any_generic, 1u);                 // sticky, per stream: the host launches the checked kernel only if set
+        const uint32_t flags = (any1 ? BF_GENERIC_SLOW_PATH : 0u) | (any2 ? BF_GENERIC_SLOW_PATH_HALF : 0u);
+        batch_flags[b] = flags;
+        if (flags) atomicOr(any_generic, flags);            // sticky, per stream: the host launches the checked kernel only if set
     }
 
     // Point windows: 40 bits of my word sequence from each point's first bit. A point's window can reach two words past
@@ -817,6 +881,14 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_pack_words(const uint32_
     for (uint32_t r = 0; r < r1 - r0; ++r) dst[(size_t)r * 64] = src[(size_t)r * PCR_WORKGROUP_SIZE];
 }
 
+// The provisional last batch of a stream that is still loading (enqueue_transcode): its block is a fixed scratch block, every wave's
+// rows uncompacted (LW_ROWS each) -- nothing to read back, nothing to allocate.
+__global__ void k_provisional_block(const uint32_t **lw_block, uint32_t *lw_wave_row, const uint32_t *scratch, int b)
+{
+    if (threadIdx.x == 0) lw_block[b] = scratch;
+    if (threadIdx.x <= (uint32_t)LWC_WAVES) lw_wave_row[(size_t)b * (LWC_WAVES + 1) + threadIdx.x] = threadIdx.x * (uint32_t)LW_ROWS;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_bounds: once per loaded batch, behind k_transcode (same launch geometry, same chunk of batches): where the batch's chains
 // fall apart into spatial clusters (BatchRuns above). Every lane decodes its chain (the plain checked form of the decode, from
@@ -838,10 +910,10 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_bounds(StreamView s, con
     __shared__ uint8_t s_outlier[PCR_WORKGROUP_SIZE];
     __shared__ float s_mean[PCR_WORKGROUP_SIZE / 64];
     __shared__ unsigned long long s_best[PCR_WORKGROUP_SIZE / 64];
-    __shared__ uint32_t s_cut[RUNS - 1];
-    __shared__ uint32_t s_box[RUNS][6];
+    __shared__ uint32_t s_cut[MAX_PARTS][RUNS - 1];
+    __shared__ uint32_t s_box[MAX_PARTS][RUNS][6];
+    __shared__ uint32_t s_all[MAX_PARTS][6];
     reinterpret_cast<uint4 *>(s_table)[tid] = reinterpret_cast<const uint4 *>(s.packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
-    if (tid < RUNS * 6) s_box[tid / 6][tid % 6] = (tid % 6) < 3 ? 0xFFFFFFFFu : 0u;
     const pcr_gpu_batch *gb = s.batches + b;
     const int32_t *sep = s.separate + gb->separate_batch_offset;
     const uint32_t sep_last = (uint32_t)min((int64_t)0x7FFFFFF0, s.separate_words + (PCR_GUARD_WORDS - 2) - gb->separate_batch_offset);
@@ -910,51 +982,82 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_bounds(StreamView s, con
     for (int k = 0; k < 3; ++k) s_centre[tid][k] = 0.5f * mn[k] + 0.5f * mx[k];
     s_outlier[tid] = outlier ? 1 : 0;
     __syncthreads();
-    float gap = -1.0f;
+    float gap0 = -1.0f;
+    uint32_t prev = 0;
     if (tid && !outlier) {
-        uint32_t prev = tid - 1;
+        prev = tid - 1;
 #pragma unroll
         for (int back = 0; back < 3; ++back) if (prev && s_outlier[prev]) --prev;
-        gap = 0.0f;
+        gap0 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) gap = fmaxf(gap, fabsf(s_centre[tid][k] - s_centre[prev][k]));
-        if (!(gap >= 0.0f) || s_outlier[prev]) gap = 0.0f;
+        for (int k = 0; k < 3; ++k) gap0 = fmaxf(gap0, fabsf(s_centre[tid][k] - s_centre[prev][k]));
+        if (!(gap0 >= 0.0f) || s_outlier[prev]) gap0 = 0.0f;
     }
-    // the RUNS - 1 largest jumps, one after the other: wave maximum of (gap, chain) by shuffles, then over the 16 waves
-    for (int round = 0; round < RUNS - 1; ++round) {
-        unsigned long long key = gap >= 0.0f ? ((unsigned long long)__float_as_uint(gap) << 32) | tid : 0ull;
+    // One record per workgroup shape and part (RUN_RECORDS): the whole batch, then its two halves side by side (every chain
+    // belongs to one of them), each cut at the RUNS - 1 largest jumps INSIDE it.
+#pragma unroll 1
+    for (int cfg = 0; cfg < 2; ++cfg) {
+        const uint32_t part_shift = 10u - (uint32_t)cfg, part = tid >> part_shift, part_first = part << part_shift;
+        const uint32_t part_waves = 16u >> cfg, wave0 = part * part_waves;
+        if (tid < 2 * RUNS * 6) s_box[tid / (RUNS * 6)][(tid / 6) % RUNS][tid % 6] = (tid % 6) < 3 ? 0xFFFFFFFFu : 0u;
+        if (tid < 2 * 6) s_all[tid / 6][tid % 6] = (tid % 6) < 3 ? 0xFFFFFFFFu : 0u;
+        // (no jump into a part's first chain, none measured against a chain of the other part)
+        float gap = (tid == part_first || prev < part_first) ? -1.0f : gap0;
+        // the RUNS - 1 largest jumps, one after the other: wave maximum of (gap, chain) by shuffles, then over the part's waves
+        for (int round = 0; round < RUNS - 1; ++round) {
+            unsigned long long key = gap >= 0.0f ? ((unsigned long long)__float_as_uint(gap) << 32) | tid : 0ull;
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, m);
-            key = key > o ? key : o;
+            for (int m = 1; m < 64; m <<= 1) {
+                const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, m);
+                key = key > o ? key : o;
+            }
+            if ((tid & 63u) == 0) s_best[tid >> 6] = key;
+            __syncthreads();
+            unsigned long long best = s_best[wave0];
+            for (uint32_t w = 1; w < part_waves; ++w) best = best > s_best[wave0 + w] ? best : s_best[wave0 + w];
+            const uint32_t cut = (uint32_t)best;                // (0 if there is no chain left to cut at: a run of no chains)
+            if (tid == cut) gap = -1.0f;
+            if (tid == part_first) s_cut[part][round] = cut ? cut : (uint32_t)PCR_WORKGROUP_SIZE;
+            __syncthreads();
         }
-        if ((tid & 63u) == 0) s_best[tid >> 6] = key;
-        __syncthreads();
-        unsigned long long best = s_best[0];
-#pragma unroll
-        for (int w = 1; w < PCR_WORKGROUP_SIZE / 64; ++w) best = best > s_best[w] ? best : s_best[w];
-        const uint32_t cut = (uint32_t)best;                // (0 if there is no chain left to cut at: a run of no chains)
-        if (tid == cut) gap = -1.0f;
-        if (tid == 0) s_cut[round] = cut ? cut : (uint32_t)PCR_WORKGROUP_SIZE;
-        __syncthreads();
-    }
-    uint32_t c0 = s_cut[0], c1 = s_cut[1], c2 = s_cut[2];
-    static_assert(RUNS == 4, "three cuts, sorted by hand");
-    if (c0 > c1) { const uint32_t t = c0; c0 = c1; c1 = t; }
-    if (c1 > c2) { const uint32_t t = c1; c1 = c2; c2 = t; }
-    if (c0 > c1) { const uint32_t t = c0; c0 = c1; c1 = t; }
-    const uint32_t run = (tid >= c0) + (tid >= c1) + (tid >= c2);
-    if (!outlier) {
+        uint32_t c0 = s_cut[part][0], c1 = s_cut[part][1], c2 = s_cut[part][2];
+        static_assert(RUNS == 4, "three cuts, sorted by hand");
+        if (c0 > c1) { const uint32_t t = c0; c0 = c1; c1 = t; }
+        if (c1 > c2) { const uint32_t t = c1; c1 = c2; c2 = t; }
+        if (c0 > c1) { const uint32_t t = c0; c0 = c1; c1 = t; }
+        const uint32_t run = (tid >= c0) + (tid >= c1) + (tid >= c2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            atomicMin(&s_box[run][k], float_order(mn[k]));
-            atomicMax(&s_box[run][3 + k], float_order(mx[k]));
+            if (!outlier) {
+                atomicMin(&s_box[part][run][k], float_order(mn[k]));
+                atomicMax(&s_box[part][run][3 + k], float_order(mx[k]));
+            }
+            // (every chain of the part, straddling ones and garbage tails included: the one window a workgroup would need)
+            atomicMin(&s_all[part][k], float_order(mn[k]));
+            atomicMax(&s_all[part][3 + k], float_order(mx[k]));
         }
+        __syncthreads();
+        // the records' words, one thread each: the parts of this shape lie back to back
+        const uint32_t nparts = 1u << cfg;
+        if (tid < nparts * RUN_WORDS) {
+            const uint32_t pi = tid / RUN_WORDS, w = tid % RUN_WORDS;
+            uint32_t *out = batch_runs + ((size_t)b * RUN_RECORDS + run_record((int)nparts, (int)pi)) * RUN_WORDS;
+            uint32_t v;
+            if (w < 4) {
+                uint32_t d0 = s_cut[pi][0], d1 = s_cut[pi][1], d2 = s_cut[pi][2];
+                if (d0 > d1) { const uint32_t t = d0; d0 = d1; d1 = t; }
+                if (d1 > d2) { const uint32_t t = d1; d1 = d2; d2 = t; }
+                if (d0 > d1) { const uint32_t t = d0; d0 = d1; d1 = t; }
+                v = w == 0 ? d0 : w == 1 ? d1 : w == 2 ? d2 : 0u;
+            } else if (w < 4 + RUNS * 6) {
+                v = __float_as_uint(float_unorder(s_box[pi][(w - 4) / 6][(w - 4) % 6]));
+            } else {
+                v = __float_as_uint(float_unorder(s_all[pi][w - 4 - RUNS * 6]));
+            }
+            out[w] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t *out = batch_runs + (size_t)b * RUN_WORDS;
-    if (tid < 4) out[tid] = tid == 0 ? c0 : tid == 1 ? c1 : tid == 2 ? c2 : 0u;
-    if (tid < RUNS * 6) out[4 + tid] = __float_as_uint(float_unorder(s_box[tid / 6][tid % 6]));
 }
 
 #ifdef PCR_EXP_TIMELINE   /* experiment: per-workgroup time stamps of k_render's phases (100 MHz wall clock) + the hardware slot it ran on */
@@ -975,12 +1078,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // BF_GENERIC_SLOW_PATH by k_transcode): escape indices are tested against the LDS pool, `wide` table values come from
 // global memory. A kernel of its own, so that the ordinary batches' loop carries neither its tests nor its code; the host
 // launches it only for streams that have such batches.
-template <int MODE, int LAYOUT, bool GENERIC>
-__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two workgroups per CU -> <= 64 VGPRs
+// PARTS: workgroups per batch. 1: 1024 threads, the batch's 1024 chains (the reference's shape, render.cu:328). 2: 512 threads,
+// chains [512 part, 512 part + 512) -- four workgroups per CU (see DYN_LDS_BYTES_HALF). Workgroup x of the grid draws part
+// (x >> 3) & 1 of list entry (x >> 4) * 8 + (x & 7): the hardware deals workgroups round-robin over the eight XCDs, so the two
+// halves of a batch run on the same XCD and the second one's table comes out of that XCD's L2.
+template <int MODE, int LAYOUT, bool GENERIC, int PARTS = 1>
+__global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(RenderArgs a)   // 8 waves/SIMD = two (four) workgroups per CU -> <= 64 VGPRs
 {
     constexpr bool COLOR_PASS = MODE == MODE_HQS_COLOR || MODE == MODE_HQS_COLOR_BC7, BC7 = MODE == MODE_HQS_COLOR_BC7;
-    // second level of the compaction: which batch is the blockIdx.x-th of my list? Every wave works it out for itself (a
-    // 64-lane inclusive prefix sum over the chunk counts, 64 chunks = 2048 batches per round): no barrier, no LDS.
+    constexpr uint32_t THREADS = PCR_WORKGROUP_SIZE / PARTS;
+    static_assert(PARTS == 1 || PARTS == 2, "whole batches or halves");
+    const uint32_t part = PARTS == 1 ? 0u : (blockIdx.x >> 3) & 1u;
     PCR_TL(0);
 #ifdef PCR_EXP_TIMELINE
     if (threadIdx.x == 0) {
@@ -997,7 +1105,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     {
         const uint32_t lane = threadIdx.x & 63u, chunks = a.order_stride / PREPASS_BATCHES;
         const uint32_t classes = GENERIC ? 1u : a.work_classes;
-        uint32_t x = blockIdx.x, found = 0xFFFFFFFFu;
+        uint32_t x = PARTS == 1 ? blockIdx.x : (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u), found = 0xFFFFFFFFu;
         for (uint32_t cls = 0; cls < classes && found == 0xFFFFFFFFu; ++cls) {                  // (uniform; one class unless the frame has a level of detail)
             const uint32_t *cc = a.chunk_count + (GENERIC ? WORK_CLASSES : cls) * PCR_MAX_PREPASS_WORKGROUPS;
             uint32_t before = 0;
@@ -1032,6 +1140,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const int npr = (int)(lod & LOD_NPR_MASK);
     const bool use_double = (lod & LOD_DOUBLE) != 0;
     const uint32_t tid = threadIdx.x;
+    const uint32_t chain = part * THREADS + tid;            // my chain of the batch's 1024
     // (the lambdas below capture these scalars, not the argument block: with `a` captured by reference and the loop body
     // instantiated five times, hipcc once kept the whole block in scratch memory)
     uint64_t *const g_fb = a.f.fb, *const g_rg = a.f.rg, *const g_ba = a.f.ba;
@@ -1048,7 +1157,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     // decoder table -> LDS (render.cu:383-395), four entries per thread, already packed by k_transcode
     const int32_t *tvalues = a.s.table_values + (size_t)b * PCR_HUFFMAN_TABLE_SIZE;   // only for `wide` entries
-    reinterpret_cast<uint4 *>(s_table)[tid] = reinterpret_cast<const uint4 *>(a.s.packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid];
+#pragma unroll
+    for (int k = 0; k < PARTS; ++k)
+        reinterpret_cast<uint4 *>(s_table)[tid + k * THREADS] = reinterpret_cast<const uint4 *>(a.s.packed_table + (size_t)b * PCR_HUFFMAN_TABLE_SIZE)[tid + k * THREADS];
 
     const pcr_gpu_batch *gb = a.s.batches + b;
     const int64_t sep_off = rec.sep_off;                    // :405
@@ -1059,47 +1170,51 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const uint32_t sep_last = (uint32_t)min((int64_t)0x7FFFFFF0, a.s.separate_words + (PCR_GUARD_WORDS - 2) - sep_off);
     auto sep_load = [&](uint32_t i) -> int32_t { return sep[min(i, sep_last)]; };
 
-    // ---- escape words of the batch -> LDS (all of them, or none) --------------------------------------------
+    // ---- escape words of my chains -> LDS (all of them, or none) ---------------------------------------------
     const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
-    const uint32_t esc_total = rec.esc_total;
-    // The pool also takes ESC_SLACK words that FOLLOW the batch's own escapes in memory, so that the reference's
-    // tail over-reads find in LDS what they would find in global memory; reads beyond even that, and
-    // batches that do not fit, go to global memory (slow variant of the decode step).
-    const uint32_t esc_lds = esc_pool_words(esc_total);
+    // [esc_first, esc_first + esc_count): the escape words of the workgroup's chains inside the batch's
+    const uint32_t esc_first = PARTS == 1 || part == 0 ? 0u : rec.esc_mid;
+    const uint32_t esc_count = PARTS == 1 ? rec.esc_total : part == 0 ? rec.esc_mid : rec.esc_total - rec.esc_mid;
+    // The pool also takes ESC_SLACK words that FOLLOW those in memory, so that the reference's tail over-reads
+    // find in LDS what they would find in global memory; reads beyond even that, and workgroups whose escapes do not fit, go
+    // to global memory (slow variant of the decode step).
+    const uint32_t esc_lds = esc_pool_words(esc_count, PARTS);
     unsigned long long *const s_win = reinterpret_cast<unsigned long long *>(s_dyn + esc_pool_bytes(esc_lds));
-    const uint32_t win_cap = (uint32_t)window_capacity(esc_total, COLOR_PASS ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES, a.dyn_lds_bytes);
-    {   // all loads of a thread in flight together, requested before the batch's escape count is known (7 per thread)
-        int32_t v[ESC_POOL_EAGER / PCR_WORKGROUP_SIZE];
+    const uint32_t win_cap = (uint32_t)window_capacity(esc_count, COLOR_PASS ? WIN_PIXEL_BYTES_HQS : WIN_PIXEL_BYTES, a.dyn_lds_bytes, PARTS);
+    {   // all loads of a thread in flight together (7-8 per thread: the pool of an ordinary batch)
+        constexpr int EAGER = PARTS == 1 ? 7 : 8;
+        int32_t v[EAGER];
 #pragma unroll
-        for (int k = 0; k < ESC_POOL_EAGER / PCR_WORKGROUP_SIZE; ++k) v[k] = sep_load(tid + k * PCR_WORKGROUP_SIZE);
+        for (int k = 0; k < EAGER; ++k) v[k] = sep_load(esc_first + tid + k * THREADS);
 #pragma unroll
-        for (int k = 0; k < ESC_POOL_EAGER / PCR_WORKGROUP_SIZE; ++k)
-            if (tid + k * PCR_WORKGROUP_SIZE < esc_lds) s_esc[tid + k * PCR_WORKGROUP_SIZE] = v[k];
-    }
-    if (esc_lds > (uint32_t)ESC_POOL_EAGER) {               // (uniform) an escape-heavy batch: the rest of its pool
-        int32_t v[(ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE];
+        for (int k = 0; k < EAGER; ++k)
+            if (tid + k * THREADS < esc_lds) s_esc[tid + k * THREADS] = v[k];
+        constexpr int REST = (esc_pool_max(PARTS) - EAGER * (int)THREADS) / (int)THREADS;
+        static_assert(REST * (int)THREADS + EAGER * (int)THREADS == esc_pool_max(PARTS), "the pool in whole rounds of the workgroup");
+        if (esc_lds > (uint32_t)EAGER * THREADS) {          // (uniform) an escape-heavy batch: the rest of its pool
+            int32_t u[REST];
 #pragma unroll
-        for (int k = 0; k < (ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE; ++k)
-            v[k] = sep_load(ESC_POOL_EAGER + tid + k * PCR_WORKGROUP_SIZE);
+            for (int k = 0; k < REST; ++k) u[k] = sep_load(esc_first + (EAGER + k) * THREADS + tid);
 #pragma unroll
-        for (int k = 0; k < (ESC_POOL_WORDS - ESC_POOL_EAGER) / PCR_WORKGROUP_SIZE; ++k) {
-            const uint32_t i = ESC_POOL_EAGER + tid + k * PCR_WORKGROUP_SIZE;
-            if (i < esc_lds) s_esc[i] = v[k];
+            for (int k = 0; k < REST; ++k) {
+                const uint32_t i = (EAGER + k) * THREADS + tid;
+                if (i < esc_lds) s_esc[i] = u[k];
+            }
         }
     }
     // :411-413 (batch-relative): my chain's next escape word, as a pointer into the pool (the LDS address travels in one
     // register: nothing to add per read)
-    const int32_t *esc_next = s_esc + (tid ? (uint32_t)ssz[tid - 1] : 0u);
+    const int32_t *esc_next = s_esc + ((chain ? (uint32_t)ssz[chain - 1] : 0u) - esc_first);
 
     // ---- framebuffer window of the batch's rectangle -> LDS --------------------------------------------------
     // Up to RUNS rectangles per batch (WinPlan): my chain scatters into the window of its run; all of them live in one array of
     // window pixels, in run order. The window is a per-lane matter (runs do not end at wave boundaries): its origin, size and
     // first pixel sit in vector registers.
-    const WinPlan *const plan_p = a.win + b;                // (read field by field: a local copy indexed in a loop lands in scratch)
+    const WinPlan *const plan_p = a.win + ((size_t)b * PARTS + part);   // (read field by field: a local copy indexed in a loop lands in scratch)
     uint32_t wpix = 0;                                      // pixels of all windows together; 0: no window for this batch
     uint32_t wx0 = 0, wy0 = 0, ww = 0, wh = 0, wbase = 0;
     {
-        const uint32_t run = (tid >= plan_p->first[0]) + (tid >= plan_p->first[1]) + (tid >= plan_p->first[2]);
+        const uint32_t run = (chain >= plan_p->first[0]) + (chain >= plan_p->first[1]) + (chain >= plan_p->first[2]);
         static_assert(RUNS == 4, "three run boundaries");
 #pragma unroll
         for (int r = 0; r < RUNS; ++r) {
@@ -1122,7 +1237,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
             const uint32_t xy = plan_p->xy[r], wh2 = plan_p->wh[r];
             const uint32_t x0 = xy & 0xFFFFu, y0 = xy >> 16, w2 = wh2 & 0xFFFFu, n = w2 * (wh2 >> 16);
             const float inv_w2 = 1.0f / (float)max(w2, 1u);
-            for (uint32_t i = tid; i < n; i += PCR_WORKGROUP_SIZE) {         // (n == 0: no such window)
+            for (uint32_t i = tid; i < n; i += THREADS) {                    // (n == 0: no such window)
                 uint32_t y, x;
                 window_row_col(i, w2, inv_w2, y, x);
                 fn(base + i, (size_t)(y0 + y) * W + x0 + x);
@@ -1131,7 +1246,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
         }
     };
     if (!COLOR_PASS) {
-        for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) s_win[i] = ~0ull;
+        for (uint32_t i = tid; i < wpix; i += THREADS) s_win[i] = ~0ull;
         // The dummy slot, behind the last window pixel: the window word of every point that has none -- outside the frustum, or
         // inside it but outside its window. It starts as 0, so the depth pre-filter below turns such a lane away without a mask
         // for "the pending point is valid" having to be kept (an off-window point's word is replaced by the global one; what its
@@ -1159,7 +1274,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     const char *lwb = nullptr;
     uint32_t lw_last = 0;
     if (LAYOUT == LAYOUT_WORDS) {
-        const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(chain >> 6);
         const uint32_t *wr = a.s.lw_wave_row + (size_t)b * (LWC_WAVES + 1) + wave;
         const uint32_t r0 = wr[0], r1 = wr[1];
         lwb = reinterpret_cast<const char *>(a.s.lw_block[b]) + (size_t)r0 * LWC_ROW_BYTES;                      // uniform per wave
@@ -1176,8 +1291,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 #else
     auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint8_t *>(pwb + byte_off); };
 #endif
-    uint32_t lwo = LAYOUT == LAYOUT_WORDS ? (tid & 63u) * 4 : tid * 4;     // byte offset of my column in the row of far0 / in the high plane's row
-    uint32_t lwo2 = PW_HI_BYTES + tid;                      // ... in the low plane's row
+    uint32_t lwo = LAYOUT == LAYOUT_WORDS ? (tid & 63u) * 4 : chain * 4;   // byte offset of my column in the row of far0 / in the high plane's row
+    uint32_t lwo2 = PW_HI_BYTES + chain;                    // ... in the low plane's row
     uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
     uint64_t bits;
     uint32_t nwin_hi = 0, nwin_lo = 0;
@@ -1194,7 +1309,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
     constexpr uint32_t SFT0 = 50;                           // (bits >> 50) & 0x3FFC = 4 x the top 12 bits of the view
     uint32_t sft = SFT0;
 
-    const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + tid) * 3;   // :421-424
+    const int32_t *sv = a.s.start_values + ((size_t)b * 1024 + chain) * 3; // :421-424
     int32_t px = sv[0], py = sv[1], pz = sv[2];
 
     const double sx = gb->scale_x, sy = gb->scale_y, sz = gb->scale_z;
@@ -1210,12 +1325,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
 
     // BC1 blocks of my chain (4 blocks of 16 points, 8 bytes each): the block of the current 16-point segment in
     // registers, the next one prefetched a whole segment (16 iterations) before its first use
-    const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors_t) + ((size_t)b * 4096 + tid);          // [segment][chain]
+    const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors_t) + ((size_t)b * 4096 + chain);        // [segment][chain]
     Bc1Palette pal = {0, 0, 0, 0};
     uint2 cnext = make_uint2(0, 0);
     if (MODE != MODE_HQS_DEPTH && !BC7) cnext = cblocks[0];
     // (BC7 colours, 16 bytes per block: the block of a segment is read at its start -- no register for a prefetched one)
-    const uint4 *blocks7 = reinterpret_cast<const uint4 *>(a.s.colors_t) + ((size_t)b * 4096 + tid);
+    const uint4 *blocks7 = reinterpret_cast<const uint4 *>(a.s.colors_t) + ((size_t)b * 4096 + chain);
     Bc7Block pal7 = {0, 0, 0, 0, 0};
 
     // Second half of rasterize() (render.cu:297-301 / depth.cu:148-151 / hqs render.cu:292-313) for the point whose
@@ -1397,7 +1512,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_render(RenderArgs a) 
                     val = *esc_next;
                 } else {
                     // outside the pool: the load is consumed inside this branch so no pending VMEM result leaves it
-                    val = sep_load((uint32_t)(esc_next - s_esc));
+                    val = sep_load(esc_first + (uint32_t)(esc_next - s_esc));
                     asm volatile("; escape word from global memory %0" : "+v"(val));
                 }
                 ++esc_next;

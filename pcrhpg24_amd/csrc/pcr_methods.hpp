@@ -343,6 +343,14 @@ struct HuffmanMemIter : HuffmanMethodBase {
     }
 };
 
+// modules/huffman_cuda/huffman_cuda.h:60-75: the reference's first Huffman method (class ComputeHuffman, registered as
+// "huffman_cuda"; commented out in its main.cpp:19, 265 in favour of huffman_mem_iter_cuda, whose kernels are the same
+// decode + {depth, BC1 colour} atomicMin with the loader's memory iteration added). The name north_star lists: the same frame
+// as HuffmanMemIter under the reference's original method name.
+struct ComputeHuffman : HuffmanMemIter {
+    ComputeHuffman(Renderer *r, std::shared_ptr<HuffmanLasData> l) : HuffmanMemIter(r, std::move(l)) { name = "huffman_cuda"; }
+};
+
 struct HuffmanHQS : HuffmanMethodBase {
     HuffmanHQS(Renderer *r, std::shared_ptr<HuffmanLasData> l) : HuffmanMethodBase(r, std::move(l))
     {

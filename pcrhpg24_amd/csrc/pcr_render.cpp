@@ -1,7 +1,7 @@
 // pcr_render — headless twin of the reference's src/main.cpp for the Huffman methods and the 10-10-10 method: create
 // the renderer, the resource and its methods, select one by name, then run update()/render() frames.
 //
-//   pcr_render <file.huffman> [--method huffman_mem_iter_cuda|huffman_hqs] [--size WxH]
+//   pcr_render <file.huffman> [--method huffman_mem_iter_cuda|huffman_hqs|huffman_cuda] [--size WxH]
 //   pcr_render <file.las>      --method loop_las_cuda                      [--size WxH]
 //              [--camera yaw pitch radius tx ty tz] [--lod 0.1] [--cull 0|1] [--frames N]
 //              [--async-load]   (.huffman: copies on the loader stream, frames draw what has arrived)
@@ -54,7 +54,7 @@ int main(int argc, char **argv)
 
         std::shared_ptr<HuffmanLasData> las_huffman;
         std::shared_ptr<ComputeLasData> las_compute;
-        std::unique_ptr<Method> m0, m1;
+        std::unique_ptr<Method> m0, m1, m2;
         if (method == "loop_las_cuda") {
             las_compute = ComputeLasData::create(path);                 // main.cpp:241 (commented out there)
             m0 = std::make_unique<ComputeLoopLasCUDA>(&renderer, las_compute);   // main.cpp:251 (commented out there)
@@ -64,8 +64,10 @@ int main(int argc, char **argv)
             las_huffman->asyncUpload = async_load;
             m0 = std::make_unique<HuffmanMemIter>(&renderer, las_huffman);   // main.cpp:266-267
             m1 = std::make_unique<HuffmanHQS>(&renderer, las_huffman);
+            m2 = std::make_unique<ComputeHuffman>(&renderer, las_huffman);   // main.cpp:265 (commented out there)
             Runtime::addMethod(m0.get());                               // main.cpp:272-273
             Runtime::addMethod(m1.get());
+            Runtime::addMethod(m2.get());
         }
         Runtime::setSelectedMethod(method);
         Method *selected = Runtime::getSelectedMethod();

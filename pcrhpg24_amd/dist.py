@@ -98,17 +98,22 @@ def _shared_stream(frame, stream):
     which pcr_set_stream reads as "the context's own stream" -- a non-blocking stream nothing orders against torch's: the
     collective then starts while the frame is still being drawn (found in round 3: a warmed-up RCCL launches fast enough to
     show it). So if torch's current stream is the default one, a stream of the frame's own becomes torch's current stream
-    until release()."""
+    until release(). NOTE: that switch is process-wide (torch.cuda.set_stream) -- torch work the caller enqueues between bind()
+    and release() lands on the frame's stream, ordered with the frame; pass an explicit non-default `stream` to avoid it.
+    Idempotent: binding a frame that is already bound keeps the stream saved by the first bind."""
     import torch
     s = stream if stream is not None else torch.cuda.current_stream(frame.device)
-    frame._prev_stream = None
+    own = getattr(frame, "_own_stream", None)
+    if own is not None and s.cuda_stream == own.cuda_stream:
+        return own                                   # bound before: torch's current stream already is the frame's own
     if s.cuda_stream == 0:
-        if getattr(frame, "_own_stream", None) is None:
-            frame._own_stream = torch.cuda.Stream(frame.device)
-        frame._own_stream.wait_stream(s)             # the frame's tensors were filled on the default stream
-        frame._prev_stream = s
-        torch.cuda.set_stream(frame._own_stream)
-        s = frame._own_stream
+        if own is None:
+            own = frame._own_stream = torch.cuda.Stream(frame.device)
+        own.wait_stream(s)                           # the frame's tensors were filled on the default stream
+        if getattr(frame, "_prev_stream", None) is None:
+            frame._prev_stream = s
+        torch.cuda.set_stream(own)
+        s = own
     return s
 
 

@@ -430,6 +430,10 @@ class Context:
     def device_framebuffer(self) -> int:
         return int(self.lib.pcr_device_framebuffer(self.h) or 0)
 
+    def framebuffer_private(self) -> None:
+        """Pointers handed out by device_framebuffer() are no longer written through: dirty tiles are used again (pcr_hip.h)."""
+        self._chk(self.lib.pcr_framebuffer_private(self.h), "pcr_framebuffer_private")
+
     def use_external_buffers(self, fb: int = 0, rg: int = 0, ba: int = 0):
         self._chk(self.lib.pcr_use_external_buffers(self.h, C.c_void_p(fb or None), C.c_void_p(rg or None), C.c_void_p(ba or None)),
                   "pcr_use_external_buffers")
@@ -465,6 +469,10 @@ class Context:
     def set_render_variant(self, variant: int) -> None:
         """Which decode variant draws a stream that has both layouts resident (pcr_hip.h: PCR_VARIANT_*)."""
         self._chk(self.lib.pcr_set_render_variant(self.h, int(variant)), "pcr_set_render_variant")
+
+    def set_workgroup_parts(self, parts: int) -> None:
+        """Workgroups per batch of the render kernels: 0 = library's choice, 1 = whole batches (1024 threads), 2 = half-batches."""
+        self._chk(self.lib.pcr_set_workgroup_parts(self.h, int(parts)), "pcr_set_workgroup_parts")
 
     def merge_min_slices(self, slices_ptr: int, nslices: int, slice_elems: int) -> None:
         self._chk(self.lib.pcr_merge_min_slices(self.h, slices_ptr, nslices, slice_elems), "pcr_merge_min_slices")
@@ -688,6 +696,12 @@ class HuffmanMemIter(_HuffmanMethod):
         ctx.render_basic(p)           # RENDER
         ctx.resolve_basic(p)          # RESOLVE
         self.last_params = p
+
+
+class ComputeHuffman(HuffmanMemIter):
+    """modules/huffman_cuda/huffman_cuda.h:60-75: the reference's first Huffman method, registered as "huffman_cuda" (commented
+    out in its main.cpp:19, 265 in favour of huffman_mem_iter_cuda: same decode + atomicMin raster). The name north_star lists."""
+    name = "huffman_cuda"
 
 
 class HuffmanHQS(_HuffmanMethod):

@@ -66,8 +66,9 @@ def test_preprocess_cli_equals_library_encoder(tmp_path):
 
 
 @pytest.mark.gpu
+# ("huffman_cuda": the reference's first name for the basic method, modules/huffman_cuda/huffman_cuda.h:66 -- the one north_star lists)
 @pytest.mark.parametrize("method,extra", [("huffman_mem_iter_cuda", []), ("huffman_hqs", []),
-                                          ("huffman_mem_iter_cuda", ["--async-load"])])
+                                          ("huffman_mem_iter_cuda", ["--async-load"]), ("huffman_cuda", [])])
 def test_render_cli_matches_oracle(tmp_path, method, extra):
     build.build_tools()
     image, _ = scenes.synth_stream(2_000_000)
@@ -84,7 +85,7 @@ def test_render_cli_matches_oracle(tmp_path, method, extra):
     fb = np.fromfile(tmp_path / "fb.u64", np.uint64)
     of = oracle.OracleFile(image.view())
     p = P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), W, H)     # Debug::LOD 0.1, culling on
-    ofb, ost = (of.render_basic(p) if method == "huffman_mem_iter_cuda" else of.render_hqs_depth(p))
+    ofb, ost = (of.render_hqs_depth(p) if method == "huffman_hqs" else of.render_basic(p))
     assert np.array_equal(fb, ofb[:W * H])
     assert info["points_iterated"] == ost["points_iterated"] and info["covered_pixels"] == int((ofb[:W * H] != 2 ** 64 - 1).sum())
     assert (tmp_path / "o.ppm").stat().st_size > W * H * 3

@@ -38,12 +38,14 @@ def load(ctx, image):
     return f
 
 
-@pytest.fixture(params=["point_windows", "words"])
+@pytest.fixture(params=["point_windows", "words", "point_windows_whole"])
 def ctx(request):
     c = P.Context(0)
+    if request.param == "point_windows_whole":          # one 1024-thread workgroup per batch (the others: the library's choice, half-batches)
+        c.set_workgroup_parts(1)
     if request.param == "words":
         c.set_stream_layout(P.Context.LAYOUT_BOTH)      # both layouts resident, the packed-words kernel forced
-    c.set_render_variant(P.Context.VARIANT_POINT_WINDOWS if request.param == "point_windows" else P.Context.VARIANT_WORDS)
+    c.set_render_variant(P.Context.VARIANT_WORDS if request.param == "words" else P.Context.VARIANT_POINT_WINDOWS)
     yield c
     c.close()
 

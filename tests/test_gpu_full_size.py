@@ -74,24 +74,29 @@ def test_hqs_passes_equal_oracle_at_full_size(big, whole):
 
 def test_both_decode_variants_agree_at_full_size(whole):
     """The stream is resident in both layouts (PCR_LAYOUT_BOTH); the packed-words variant (what PCR_VARIANT_AUTO picks for large images)
-    and the point-window variant draw bit-identical frames, basic and HQS, for both cameras."""
+    and the point-window variant draw bit-identical frames, basic and HQS, for both cameras -- and so do the two workgroup shapes
+    (one 1024-thread workgroup per batch, the reference's; two 512-thread workgroups per batch, pcr_set_workgroup_parts)."""
     try:
         for cam in ("overview", "closeup"):
             p = params(cam)
             got = {}
-            for name, v in (("point_windows", P.Context.VARIANT_POINT_WINDOWS), ("words", P.Context.VARIANT_WORDS)):
-                whole.set_render_variant(v)
-                whole.clear(); whole.render_basic(p)
-                basic = whole.read_framebuffer(full=True)
-                st_basic = whole.stats()
-                whole.clear(); whole.render_hqs_depth(p); whole.render_hqs_color(p)
-                got[name] = (basic, st_basic, whole.read_framebuffer(full=True), *whole.read_accum(full=True))
-            a, b = got["point_windows"], got["words"]
-            assert a[1] == b[1]
-            for x, y in zip((a[0], a[2], a[3], a[4]), (b[0], b[2], b[3], b[4])):
-                assert np.array_equal(x, y), cam
+            for parts in (1, 2):
+                whole.set_workgroup_parts(parts)
+                for name, v in (("point_windows", P.Context.VARIANT_POINT_WINDOWS), ("words", P.Context.VARIANT_WORDS)):
+                    whole.set_render_variant(v)
+                    whole.clear(); whole.render_basic(p)
+                    basic = whole.read_framebuffer(full=True)
+                    st_basic = whole.stats()
+                    whole.clear(); whole.render_hqs_depth(p); whole.render_hqs_color(p)
+                    got[name, parts] = (basic, st_basic, whole.read_framebuffer(full=True), *whole.read_accum(full=True))
+            a = got["point_windows", 1]
+            for key, b in got.items():
+                assert a[1] == b[1], (cam, key)
+                for x, y in zip((a[0], a[2], a[3], a[4]), (b[0], b[2], b[3], b[4])):
+                    assert np.array_equal(x, y), (cam, key)
     finally:
         whole.set_render_variant(P.Context.VARIANT_AUTO)
+        whole.set_workgroup_parts(0)
 
 
 def test_two_shards_merge_to_the_whole(big, whole):

@@ -12,10 +12,17 @@ W, H = 640, 360
 
 # Every test of this module runs once per decode variant: "point_windows" (the default layout's own kernel), "words" on a
 # stream loaded with PCR_LAYOUT_BOTH (what PCR_VARIANT_AUTO then picks for images with few batches per pixel), and "words_only"
-# on a stream loaded with PCR_LAYOUT_WORDS (no point windows in HBM at all).
-@pytest.fixture(scope="module", params=["point_windows", "words", "words_only"])
+# on a stream loaded with PCR_LAYOUT_WORDS (no point windows in HBM at all). Those draw with the library's choice of workgroup
+# shape (half-batches: two 512-thread workgroups per batch); "*_whole" forces the reference's shape, one 1024-thread workgroup per
+# batch (pcr_set_workgroup_parts).
+@pytest.fixture(scope="module", params=["point_windows", "words", "words_only", "point_windows_whole", "words_whole"])
 def renderer(request):
     r = P.Renderer(W, H, device=0)
+    kind = request.param
+    if kind.endswith("_whole"):
+        r.ctx.set_workgroup_parts(1)
+        kind = kind[:-len("_whole")]
+    request = type("R", (), {"param": kind})
     if request.param == "words_only":
         r.ctx.set_stream_layout(P.Context.LAYOUT_WORDS)
     else:
@@ -138,8 +145,9 @@ def test_method_plugins_render_like_reference_session(stream200k):
         las = P.HuffmanLasData.create(nb)
         P.Runtime.addMethod(P.HuffmanMemIter(r, las))
         P.Runtime.addMethod(P.HuffmanHQS(r, las))
+        P.Runtime.addMethod(P.ComputeHuffman(r, las))         # "huffman_cuda", modules/huffman_cuda/huffman_cuda.h:66
         r.set_camera(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0))
-        for name in ("huffman_mem_iter_cuda", "huffman_hqs"):
+        for name in ("huffman_mem_iter_cuda", "huffman_hqs", "huffman_cuda"):
             P.Runtime.setSelectedMethod(name)
             m = P.Runtime.getSelectedMethod()
             m.update(r)

@@ -67,13 +67,15 @@ def check_frames(ctx, of, local_first, count, y_centre):
             assert drawn > 0.2 * count and 0.03 * drawn * 65536 < ost["points_iterated"] < 0.9 * drawn * 65536, ost
         else:
             assert ost["points_iterated"] == count * 65536
-        for variant in (P.Context.VARIANT_POINT_WINDOWS, P.Context.VARIANT_WORDS):
+        for variant, parts in ((P.Context.VARIANT_POINT_WINDOWS, 0), (P.Context.VARIANT_WORDS, 0), (P.Context.VARIANT_POINT_WINDOWS, 1)):
             ctx.set_render_variant(variant)
+            ctx.set_workgroup_parts(parts)          # 0: the library's choice (half-batches), 1: one 1024-thread workgroup per batch
             ctx.frame_begin(p); ctx.render_basic(p); ctx.resolve_basic(p)
             assert ctx.stats() == ost, (name, variant)
             assert np.array_equal(ctx.read_framebuffer(full=True), ofb), (name, variant)
             assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(p, ofb)), (name, variant)
     ctx.set_render_variant(P.Context.VARIANT_AUTO)
+    ctx.set_workgroup_parts(0)
 
 
 @pytest.fixture(scope="module")

@@ -16,11 +16,12 @@ W, H = 1000, 600          # (not a multiple of the tile size in either direction
 EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-@pytest.fixture(scope="module")
-def loaded():
+@pytest.fixture(scope="module", params=["half_batches", "whole_batches"])
+def loaded(request):
     nb, _ = scenes.synth_stream(3_000_000)
     of = oracle.OracleFile(nb.view())
     ctx = P.Context(0)
+    ctx.set_workgroup_parts(1 if request.param == "whole_batches" else 0)      # (0: the library's choice, two 512-thread workgroups per batch)
     ctx.set_image_size(W, H)
     hf = P.HuffmanFile(nb)
     ctx.stream_begin(hf.header())
@@ -142,3 +143,82 @@ def test_garbage_tails_land_anywhere_and_are_cleared():
             assert np.all(ctx.read_framebuffer(full=True) == EMPTY)
     finally:
         r.ctx.close()
+
+
+@pytest.mark.parametrize("parts", [0, 1])
+def test_garbage_tails_under_per_run_windows(parts):
+    """when a batch's own rectangle outgrows the LDS, its windows are the rectangles of its runs of chains, whose boxes
+    include the chains' garbage tails and may stick out of the rectangle the prepass marks the dirty tiles under. A
+    point inside such a window is never tested against that rectangle, so the windows are cut to it (plan_windows). Large images
+    and near cameras over the two reference-packed fixtures with tails: every turn's image and the emptied framebuffer are exact."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    for name in ("ref_packed_lowentropy.huffman", "ref_packed_batch.huffman"):
+        data = open(os.path.join(gold, name), "rb").read()
+        of = oracle.OracleFile(data)
+        w, h = 3000, 2000
+        r = P.Renderer(w, h, device=0)
+        try:
+            r.ctx.set_workgroup_parts(parts)
+            P.HuffmanLasData.create(data).load_all(r)
+            ctx = r.ctx
+            seq = [scenes.with_flags(P.camera_orbit(yaw, pitch, radius, (5.0, 5.0, 3.0), w, h), lod_percent=100, cull=0)
+                   for yaw, pitch, radius in ((0.7, -0.5, 30.0), (-0.4, -0.6, 12.0), (2.0, -0.3, 60.0), (0.1, -1.2, 20.0), (0.7, -0.5, 30.0))]
+            ctx.frame_begin(seq[0])
+            for k, p in enumerate(seq):
+                nxt = seq[(k + 1) % len(seq)]
+                ctx.render_basic(p)
+                ofb, _ = of.render_basic(p)
+                assert np.array_equal(ctx.read_framebuffer(full=True), ofb), (name, k)
+                ctx.frame_turn(p, nxt)
+                assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(p, ofb)), (name, k)
+                assert np.all(ctx.read_framebuffer(full=True) == EMPTY), (name, k)
+        finally:
+            r.ctx.close()
+
+
+def test_a_pointer_fetched_once_and_written_every_frame(loaded):
+    """an integrator fetches pcr_device_framebuffer ONCE and merges into the context's own framebuffer every frame
+    (their own collective, say) -- outside the tiles the library marked. From the getter on every turn walks the whole frame; after
+    pcr_framebuffer_private the tiles are used again. Also: pcr_set_int64_mergeable between turns changes the empty word everywhere."""
+    import torch
+    ctx, of = loaded
+    a, b = cams()[1], cams()[2]              # left part / right part of the scene: disjoint tiles
+    fa, fb_b = of.render_basic(a)[0], of.render_basic(b)[0]
+    n = W * (H + 1) + 1
+    ptr = ctx.device_framebuffer()           # fetched once, before the loop
+    want = np.minimum(fa, fb_b)
+    merged = torch.from_numpy(want.view(np.int64).copy()).cuda()
+    ctx.frame_begin(a)
+    for k in range(3):
+        ctx.render_basic(a)
+        ctx.synchronize()
+        # the integrator's own merge through that pointer: b's pixels land in tiles a's prepass never marked
+        _device_view(ptr, n).copy_(merged)
+        torch.cuda.synchronize()
+        ctx.frame_turn(a, a)
+        assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(a, want)), k
+        assert np.all(ctx.read_framebuffer(full=True) == EMPTY), k
+    ctx.framebuffer_private()
+    ctx.frame_begin(a); ctx.render_basic(a); ctx.frame_turn(a, b)
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(a, fa))
+    ctx.render_basic(b); ctx.frame_turn(b, a)
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(b, fb_b))
+    # the empty word changes between two turns: the clear that follows is a full one
+    ctx.set_int64_mergeable(True)
+    ctx.render_basic(a); ctx.frame_turn(a, b)
+    assert np.all(ctx.read_framebuffer(full=True) == EMPTY)     # (reads map the context's empty word to the reference's)
+    # ... and back: a tile-limited turn would leave INT64_MAX words in the tiles nothing was drawn in, visible as pixels now
+    ctx.set_int64_mergeable(False)
+    ctx.render_basic(b); ctx.frame_turn(b, a)
+    assert np.all(ctx.read_framebuffer(full=True) == EMPTY)
+    assert np.array_equal(ctx.read_rgba(), oracle.resolve_basic(b, fb_b))
+
+
+def _device_view(ptr, n):
+    """torch int64 view of n words of device memory at ptr (the integrator's side of pcr_device_framebuffer)."""
+    import torch
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Arr(), device="cuda")

@@ -21,11 +21,19 @@ ctx.frame_begin(p)
 for _ in range(300):
     ctx.render_basic(p); ctx.frame_turn(p, p)
 ctx.synchronize()
+parts = int(os.environ.get("PCR_PARTS", "2"))
+batches = nb
+if parts == 2:
+    nb = ((nb + 7) // 8) * 16                 # workgroups of the grid (half-batches; the padding ones never stamp)
+waves = 16 // parts
 lib = N.hip_lib()
 lib.pcr_exp_read_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 t = np.zeros(nb * 8, np.uint64)
 assert lib.pcr_exp_read_timeline(ctx.h, t.ctypes.data, t.size) == 0
 t = t.reshape(nb, 8)
+live = t[:, 5] > 0
+t = t[live]
+nb = int(live.sum())
 t0 = t[:, 0].min()
 us = (t[:, :6].astype(np.int64) - int(t0)) / 100.0         # 100 MHz -> microseconds
 hw = t[:, 7]
@@ -50,9 +58,9 @@ for x in ts:
     res = ((us[:, 0] <= x) & (us[:, 5] > x)).sum(); loop = ((us[:, 2] <= x) & (us[:, 3] > x)).sum()
     print("%7.1f : %4d %4d" % (x, res, loop))
 lib.pcr_exp_read_wave_ends.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-we = np.zeros(nb * 16, np.uint64)
+we = np.zeros(live.size * 16, np.uint64)
 assert lib.pcr_exp_read_wave_ends(ctx.h, we.ctypes.data, we.size) == 0
-we = (we.reshape(nb, 16).astype(np.int64) - int(t0)) / 100.0
+we = (we.reshape(-1, 16)[live][:, :waves].astype(np.int64) - int(t0)) / 100.0
 rel = we - us[:, 2:3]                       # loop duration per wave
 print("per-wave loop duration: mean %.1f  p10 %.1f p50 %.1f p90 %.1f max %.1f us" % (rel.mean(), *np.percentile(rel, [10, 50, 90]), rel.max()))
 print("mean loop duration by wave index   :", np.round(rel.mean(axis=0), 1))
