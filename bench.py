@@ -53,17 +53,18 @@ def parse_args():
     ap.add_argument("--method", choices=["basic", "hqs"], default="basic")
     ap.add_argument("--lod", type=int, default=100, help="LOD percent (uPointFormat); 100 = all 64 points per chain")
     ap.add_argument("--cull", type=int, default=0)
-    ap.add_argument("--camera", choices=["overview", "closeup"], default="overview")
+    ap.add_argument("--camera", choices=["overview", "closeup", "half"], default="overview")
     ap.add_argument("--layout", choices=["point_windows", "words"], default="point_windows",
                     help="HBM layout of the resident stream = decode variant of the timed steps (pcr_set_stream_layout)")
     ap.add_argument("--merge", choices=["reduce", "allreduce", "sliced", "sliced_p2p"], default="reduce",
                     help="multi-GPU exchange of the basic method: min-reduce the partial framebuffers to rank 0 (the display "
                          "rank), all-reduce them, or cut the frame into N slices: reduce-scatter (sliced_p2p, C++ layer only: all-to-all "
                          "+ local min), resolve of the own slice, gather of the image")
-    ap.add_argument("--transport", choices=["torch", "rccl", "auto"], default="torch",
-                    help="N > 1: who calls RCCL. torch (default until the C++ layer has met a peer on hardware): torch.distributed "
-                         "collectives on torch-owned int64 frames; rccl = the C++ layer (include/pcr_dist.h: ncclUint64 min in place on "
-                         "the context's stream); auto = rccl after one frame of each has produced the same merged image on rank 0, torch otherwise")
+    ap.add_argument("--transport", choices=["torch", "rccl", "auto"], default="auto",
+                    help="N > 1: who calls RCCL. auto (default): the C++ layer (include/pcr_dist.h: ncclUint64 min in place on the "
+                         "context's stream -- north_star's 'host code stays C++') once one frame merged by it and one merged through "
+                         "torch.distributed have produced the same image on rank 0, the torch transport otherwise; torch = torch.distributed "
+                         "collectives on torch-owned int64 frames; rccl = the C++ layer unchecked")
     ap.add_argument("--batches", type=int, default=0, help="experiments: load only the first N batches of this rank's shard")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +81,8 @@ def camera(P, name, w, h):
     # the synthetic tile is 1 km x 1 km, heights 0..80 m (csrc/pcr_encoder.cpp Scene)
     if name == "overview":     # camera A: whole tile in the frustum
         return P.camera_orbit(-0.15, -0.57, 1500.0, (500.0, 500.0, 40.0), w, h)
+    if name == "half":         # camera C: the overview camera moved sideways and a little closer -- about half of the tile's batches (52 %)
+        return P.camera_orbit(-0.15, -0.57, 1100.0, (-300.0, 500.0, 40.0), w, h)     # lie outside the frustum, the others fill the image
     return P.camera_orbit(-1.68, -0.39, 70.0, (300.0, 20.0, 45.0), w, h)   # camera B: close-up, heavy overdraw
 
 
@@ -98,6 +101,91 @@ def load_traffic(P, args):
             (args.points, args.method, args.width, args.lod, args.cull, args.camera):
         return {}, "profiles/pmc_traffic_latest.json is for another workload: not quoted"
     return t.get("hbm_bytes_per_launch", {}), "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, kernel %s; not measured by this run)" % ver
+
+
+def las_row(P, device, args):
+    """secondary.las: the 10-10-10 method (modules/compute_loop_las_cuda) on a tile-ordered cloud of the same 1e8
+    synthetic points: clear + k_las_prepass + k_las_render + resolve per step, full-size parity against pcr_oracle_render_las."""
+    import numpy as np
+    n, seed = POINTS_ONE_GPU, args.seed
+    t0 = time.time()
+    x, y, z, c = P.synth_points(n, seed, 0, n)
+    las = P.synth_las_info(n, seed)
+    side = max(1, int(round(1_000_000 / max(1.0, (n / 65536) ** 0.5))))          # spatially coherent file order: ~65 536-point square tiles
+    idx = np.argsort((y // side).astype(np.int64) * 4096 + x // side, kind="stable")
+    x, y, z, c = x[idx], y[idx], z[idx], c[idx]
+    q = P.las_quantize(x, y, z, c, las)
+    t_prep = time.time() - t0
+    ctx = P.Context(device)
+    try:
+        ctx.set_image_size(args.width, args.height)
+        ctx.las_begin(n)
+        nb = len(q[0])
+        XB = type(q[0][0])
+        for b0 in range(0, nb, 100):
+            b1 = min(nb, b0 + 100)
+            ctx.las_upload(b0, (XB * (b1 - b0)).from_buffer(q[0], b0 * 64), *(a[b0 * 65536:b1 * 65536] for a in q[1:]))
+        p = camera(P, "overview", args.width, args.height)
+        p.enable_frustum_culling = 0
+
+        def step():
+            ctx.clear(); ctx.render_las(p); ctx.resolve_las(p)
+        for _ in range(5):
+            step()
+        ctx.synchronize()
+        ctx.kernel_timing(1)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        ctx.synchronize()
+        e = time.perf_counter() - t0
+        k_ms, _ = ctx.kernel_timing_read()
+        ctx.kernel_timing(0)
+        st = ctx.stats()
+        alg = ctx.las_algorithmic_bytes
+        parity = None
+        if not args.no_cpu_baseline:
+            from tests import oracle
+            ctx.clear(); ctx.render_las(p)
+            ofb, ost = oracle.render_las(*q[:4], p)
+            parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb)) and ost == ctx.stats()
+        return {"what": "10-10-10 method (loop_las_cuda, reference modules/compute_loop_las_cuda/render.cu:204-327): %d points in tile order, %dx%d, "
+                        "overview camera, cull 0" % (n, args.width, args.height),
+                "method": "loop_las_cuda", "steps": 20, "ms_per_step": round(1e3 * e / 20, 4), "points_per_step": int(st["points_iterated"]),
+                "Mpoints_per_s": round(st["points_iterated"] / (e / 20) / 1e6, 1), "kernel": "k_las_render", "kernel_ms": round(k_ms, 4),
+                "algorithmic_bytes": alg, "bytes_per_point": round(alg / max(1, st["points_iterated"]), 3),
+                "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else None,
+                "parity_full_size": parity, "prepare_s": round(t_prep, 2)}
+    finally:
+        ctx.close()
+
+
+def encoder_row(P, device, args, nthreads):
+    """secondary.encoder: the GPU encoder (include/pcr_gpu_encode.h, reference src/preprocess.cpp:233-801) on 2e7 points: host arrays in,
+    .huffman image out (PCIe both ways inside the time), SHA-256 against the CPU encoder's image of the same points."""
+    import hashlib
+    n = 20_000_000
+    x, y, z, c = P.synth_points(n, args.seed, 0, n)
+    las = P.synth_las_info(n, args.seed)
+    ctx = P.Context(device)
+    try:
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            gpu, st = ctx.gpu_encode_points(x, y, z, c, las, morton_sort=True)
+            best = min(best, time.perf_counter() - t0)
+        row = {"what": "GPU encoder: %d synthetic points, Morton sort + per-batch Huffman + (time, lane) interleave + BC1; host arrays -> file image" % n,
+               "points": n, "batches": int(st["num_batches"]), "seconds": round(best, 3), "Mpoints_per_s": round(n / best / 1e6, 1),
+               "sha256": hashlib.sha256(gpu.view()).hexdigest()}
+        if not args.no_cpu_baseline:
+            t0 = time.perf_counter()
+            cpu, st_cpu = P.encode_points(x, y, z, c, las, morton_sort=True, nthreads=nthreads)
+            t_cpu = time.perf_counter() - t0
+            row["cpu_encoder"] = {"seconds": round(t_cpu, 3), "Mpoints_per_s": round(n / t_cpu / 1e6, 1), "threads": nthreads}
+            row["identical_to_cpu_encoder"] = hashlib.sha256(cpu.view()).hexdigest() == row["sha256"] and st_cpu == st
+        return row
+    finally:
+        ctx.close()
 
 
 def scaling_base(P, total_points, args):
@@ -406,6 +494,19 @@ def main():
             s1 = time.perf_counter() - t0
             cpu_baseline["single_core"] = {"value": round(ost1["points_iterated"] / s1 / 1e6, 3), "unit": "Mpoints/s",
                                            "sample": "first %d batches (%d points), %.1f s wall" % (one, ost1["points_iterated"], s1)}
+        if args.method == "basic" and (os.cpu_count() or 1) > nthreads:     # ... and on ALL host cores
+            allc = os.cpu_count()
+            t0 = time.perf_counter()
+            _, osta = of.render_basic(p.copy(), first=0, count=sample, nthreads=allc)
+            sa, fr = time.perf_counter() - t0, 1
+            while sa * allc < 20.0 and fr < 8:
+                t0 = time.perf_counter()
+                of.render_basic(p.copy(), first=0, count=sample, nthreads=allc)
+                sa += time.perf_counter() - t0
+                fr += 1
+            cpu_baseline["all_cores"] = {"value": round(fr * osta["points_iterated"] / sa / 1e6, 3), "unit": "Mpoints/s", "cores": allc,
+                                         "sample": "%d frame(s) of %d batches, one thread per host core (a framebuffer each, merged in parallel), %.2f s wall"
+                                                   % (fr, sample, sa)}
         if sample == nb:        # same inputs end to end: compare the whole framebuffer, bit for bit
             ctx.clear(); (ctx.render_basic if args.method == "basic" else ctx.render_hqs_depth)(p)
             parity = bool(np.array_equal(ctx.read_framebuffer(full=True), ofb))
@@ -419,20 +520,22 @@ def main():
     secondary = None
     if world == 1 and not use_dist and not args.no_secondary:
         secondary = {}
-        rows = (("lod10_cull1", "basic", args.width, args.height, 10, 1, "LOD 10 % + frustum culling: the reference's defaults (include/Debug.h:21-23)"),
-                ("hqs", "hqs", args.width, args.height, 100, 0, "HQS two-pass (BASELINE configs[2])"),
-                ("4096_cull1", "basic", 4096, 4096, 100, 1, "4096x4096 with culling (BASELINE configs[4], one GPU's view of it)"))
-        for name, method, w, h, lod, cull, what in rows:
+        rows = (("lod10_cull1", "basic", args.width, args.height, 10, 1, args.camera, "LOD 10 % + frustum culling: the reference's defaults (include/Debug.h:21-23)"),
+                ("hqs", "hqs", args.width, args.height, 100, 0, args.camera, "HQS two-pass (BASELINE configs[2])"),
+                ("4096_cull1", "basic", 4096, 4096, 100, 1, args.camera, "4096x4096 with culling (BASELINE configs[4], one GPU's view of it); this camera sees every batch"),
+                ("4096_cull1_half", "basic", 4096, 4096, 100, 1, "half", "4096x4096 with culling, a camera that leaves about half of the batches outside the frustum: "
+                                                                       "the prepass's ballot / prefix-sum compaction is on the timed path"))
+        for name, method, w, h, lod, cull, cam, what in rows:
             if (w, h) != (args.width, args.height):
                 ctx.set_image_size(w, h)
-            q = camera(P, args.camera, w, h)
+            q = camera(P, cam, w, h)
             q.lod_percent, q.enable_frustum_culling = lod, cull
             s_step = single_gpu_step(method, q)
             e, k_ms, _, _ = timed_run(s_step, method, q, 20, 3, 0.2)
             sst = ctx.stats()
             whole = lod >= 100 and sst["batches_culled"] == 0
             ab = ctx.algorithmic_bytes if whole else ctx.last_frame_algorithmic_bytes
-            secondary[name] = {"what": what, "method": method, "width": w, "height": h, "lod_percent": lod, "cull": cull, "steps": 20,
+            secondary[name] = {"what": what, "method": method, "width": w, "height": h, "lod_percent": lod, "cull": cull, "camera": cam, "steps": 20,
                                "ms_per_step": round(1e3 * e / 20, 4), "points_per_step": int(sst["points_iterated"]),
                                "Mpoints_per_s": round(sst["points_iterated"] / (e / 20) / 1e6, 1),
                                "batches_culled": int(sst["batches_culled"]),
@@ -448,6 +551,11 @@ def main():
         n2 = min(args.steps, 100)
         e2, k2, _, _ = timed_run(single_gpu_step(args.method, p), args.method, p, n2, args.warmup, min(args.preroll, 0.3))
         variants[other] = variant_record(other, 1e3 * e2 / n2, k2, ctx.resident_bytes)
+
+    # ---- the rows SURVEY 8f built next, on contexts of their own (N == 1 only): the 10-10-10 method and the GPU encoder -------------
+    if world == 1 and not use_dist and not args.no_secondary and rank == 0:
+        secondary["las"] = las_row(P, local_rank, args)
+        secondary["encoder"] = encoder_row(P, local_rank, args, nthreads)
 
     if args.method == "hqs":
         merge_desc = "min all-reduce of the depth + sum %s of the colour sums" % (
@@ -474,6 +582,9 @@ def main():
                        "escape_fraction": round(enc["escaped_symbols"] / enc["total_symbols"], 5),
                        "parallelism": ("contiguous batch shards x%d + RCCL %s" % (world, merge_desc)) if use_dist else "single GPU",
                        "transport": transport, "transport_check": transport_check,
+                       "rccl_ranks": native.comm_ranks() if native is not None else (dist.get_world_size() if use_dist else None),
+                       "rccl_ranks_how": "ncclCommCount of the C++ layer's communicator" if native is not None else
+                                         ("world size of torch.distributed's nccl group" if use_dist else None),
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "preroll_s": args.preroll,
                        "first_frame_ms": round(first_frame_ms, 3)},
             "step_ms": {"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4), "max": round(max(step_ms), 4),

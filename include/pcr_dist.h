@@ -57,6 +57,9 @@ int pcr_dist_create_local(pcr_ctx *const *ctxs, int n, pcr_dist **out);
 void pcr_dist_destroy(pcr_dist *d);
 int pcr_dist_rank(const pcr_dist *d);
 int pcr_dist_world(const pcr_dist *d);
+/* How many ranks RCCL itself says the communicator has (ncclCommCount): what a bench line quotes as `rccl_ranks`, so that a
+ * multi-GPU number can be told from one taken on a one-rank communicator. 0: no communicator, -1: RCCL refused. */
+int pcr_dist_comm_ranks(const pcr_dist *d);
 
 /* Bracket the collectives of several ranks issued by one thread (ncclGroupStart / ncclGroupEnd). */
 int pcr_dist_group_begin(void);

@@ -523,18 +523,44 @@ int pcr_oracle_count_depth_ties(const pcr_oracle_stream *s, const pcr_render_par
     return 0;
 }
 
-/* Multi-threaded basic render for the CPU baseline: batches striped over threads,
- * per-thread framebuffer, final min merge. */
+/* Multi-threaded basic render for the CPU baseline: batches handed out one at a time (an atomic counter), a
+ * framebuffer per thread that the thread itself clears, then every thread min-merges its share of the pixels over all the
+ * buffers -- nothing serial left but thread creation, so that the row "all host cores" of bench.py (256 on the GPU box) measures the
+ * render and not a 4 GB memset by one core. min is associative and commutative: the frame does not depend on who drew what. */
 typedef struct {
     const pcr_oracle_stream *s; const pcr_render_params *p;
-    int64_t first, count; int tid, nthreads; uint64_t *fb; pcr_render_stats stats;
-} mt_job;
+    int64_t first, count; int nthreads; size_t n;
+    uint64_t **fbs; int64_t next; pthread_barrier_t bar; int failed;
+} mt_shared;
+typedef struct { mt_shared *sh; int tid; pcr_render_stats stats; } mt_job;
 
 static void *mt_worker(void *arg)
 {
     mt_job *j = (mt_job *)arg;
-    for (int64_t b = j->first + j->tid; b < j->first + j->count; b += j->nthreads)
-        render_range(j->s, j->p, MODE_BASIC, b, 1, j->fb, NULL, NULL, &j->stats);
+    mt_shared *sh = j->sh;
+    uint64_t *fb = sh->fbs[j->tid];
+    if (j->tid) {
+        fb = (uint64_t *)malloc(sh->n * 8);
+        if (fb) memset(fb, 0xFF, sh->n * 8); else __atomic_store_n(&sh->failed, 1, __ATOMIC_RELAXED);
+        sh->fbs[j->tid] = fb;
+    }
+    if (fb)
+        for (;;) {
+            const int64_t b = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
+            if (b >= sh->count) break;
+            render_range(sh->s, sh->p, MODE_BASIC, sh->first + b, 1, fb, NULL, NULL, &j->stats);
+        }
+    pthread_barrier_wait(&sh->bar);
+    /* my share of the pixels, over every thread's buffer */
+    const size_t lo = sh->n * (size_t)j->tid / (size_t)sh->nthreads, hi = sh->n * ((size_t)j->tid + 1) / (size_t)sh->nthreads;
+    uint64_t *out = sh->fbs[0];
+    for (int t = 1; t < sh->nthreads; ++t) {
+        const uint64_t *src = sh->fbs[t];
+        if (!src) continue;
+        for (size_t i = lo; i < hi; ++i) if (src[i] < out[i]) out[i] = src[i];
+    }
+    pthread_barrier_wait(&sh->bar);
+    if (j->tid) free(fb);
     return NULL;
 }
 
@@ -543,24 +569,27 @@ int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_para
                                pcr_render_stats *stats)
 {
     if (nthreads < 1) nthreads = 1;
-    size_t n = pcr_fb_elems(p->width, p->height);
+    if ((int64_t)nthreads > count && count > 0) nthreads = (int)count;
+    mt_shared sh;
+    memset(&sh, 0, sizeof sh);
+    sh.s = s; sh.p = p; sh.first = first; sh.count = count; sh.nthreads = nthreads; sh.n = pcr_fb_elems(p->width, p->height);
+    sh.fbs = (uint64_t **)calloc((size_t)nthreads, sizeof *sh.fbs);
     mt_job *jobs = (mt_job *)calloc((size_t)nthreads, sizeof *jobs);
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
-    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    if (!sh.fbs || !jobs || !th || pthread_barrier_init(&sh.bar, NULL, (unsigned)nthreads)) { free(sh.fbs); free(jobs); free(th); return -1; }
+    sh.fbs[0] = fb;
+    int started = 0;
     for (int t = 0; t < nthreads; ++t) {
-        jobs[t].s = s; jobs[t].p = p; jobs[t].first = first; jobs[t].count = count;
-        jobs[t].tid = t; jobs[t].nthreads = nthreads;
-        jobs[t].fb = t == 0 ? fb : (uint64_t *)malloc(n * 8);
-        if (!jobs[t].fb) return -1;
-        if (t) memset(jobs[t].fb, 0xFF, n * 8);
-        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+        jobs[t].sh = &sh; jobs[t].tid = t;
+        if (pthread_create(&th[t], NULL, mt_worker, &jobs[t])) break;
+        ++started;
+    }
+    if (started != nthreads) {      /* (the barrier would never open: a box that refuses threads is not one to take a baseline on) */
+        fprintf(stderr, "pcr_oracle_render_basic_mt: only %d of %d threads could be started\n", started, nthreads);
+        abort();
     }
     for (int t = 0; t < nthreads; ++t) {
         pthread_join(th[t], NULL);
-        if (t) {
-            for (size_t i = 0; i < n; ++i) if (jobs[t].fb[i] < fb[i]) fb[i] = jobs[t].fb[i];
-            free(jobs[t].fb);
-        }
         if (stats) {
             stats->batches_total += jobs[t].stats.batches_total;
             stats->batches_culled += jobs[t].stats.batches_culled;
@@ -568,8 +597,10 @@ int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_para
             stats->batches_double += jobs[t].stats.batches_double;
         }
     }
-    free(jobs); free(th);
-    return 0;
+    const int failed = sh.failed;
+    pthread_barrier_destroy(&sh.bar);
+    free(sh.fbs); free(jobs); free(th);
+    return failed ? -1 : 0;
 }
 
 /* ------------------------------------------------------------------------------------------------

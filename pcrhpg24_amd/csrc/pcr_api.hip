@@ -128,6 +128,7 @@ struct pcr_ctx {
     uint32_t *d_xyz12 = nullptr, *d_xyz8 = nullptr, *d_xyz4 = nullptr, *d_point_rgba = nullptr;
     int32_t *d_las_level = nullptr;
     uint2 *d_las_win = nullptr;
+    uint32_t *d_las_order = nullptr, *d_las_chunk_count = nullptr;      // LasArgs::order / chunk_count
 
     // method (framebuffers)
     int width = 0, height = 0;
@@ -224,7 +225,7 @@ void free_stream_buffers(pcr_ctx *c)
 void free_las_buffers(pcr_ctx *c)
 {
     dfree(c->d_xyzb); dfree(c->d_xyz12); dfree(c->d_xyz8); dfree(c->d_xyz4); dfree(c->d_point_rgba);
-    dfree(c->d_las_level); dfree(c->d_las_win);
+    dfree(c->d_las_level); dfree(c->d_las_win); dfree(c->d_las_order); dfree(c->d_las_chunk_count);
     c->las_open = false; c->las_capacity = c->las_loaded = 0;
 }
 
@@ -1191,7 +1192,9 @@ int pcr_las_begin(pcr_ctx *c, int64_t num_points)
     if ((rc = dalloc_zero(c, c->d_xyzb, (size_t)nB)) || (rc = dalloc_zero(c, c->d_xyz12, slots)) ||
         (rc = dalloc_zero(c, c->d_xyz8, slots)) || (rc = dalloc_zero(c, c->d_xyz4, slots)) ||
         (rc = dalloc_zero(c, c->d_point_rgba, slots)) || (rc = dalloc_zero(c, c->d_las_level, (size_t)nB)) ||
-        (rc = dalloc_zero(c, c->d_las_win, (size_t)nB))) {
+        (rc = dalloc_zero(c, c->d_las_win, (size_t)nB)) ||
+        (rc = dalloc_zero(c, c->d_las_order, (size_t)((nB + LAS_PREPASS_BATCHES - 1) / LAS_PREPASS_BATCHES) * LAS_PREPASS_BATCHES)) ||
+        (rc = dalloc_zero(c, c->d_las_chunk_count, (size_t)LAS_CLASSES * (size_t)((nB + LAS_PREPASS_BATCHES - 1) / LAS_PREPASS_BATCHES)))) {
         free_las_buffers(c);
         return rc == PCR_E_HIP ? set_err(c, PCR_E_NOMEM, "out of device memory for %lld batches", (long long)nB) : rc;
     }
@@ -1262,6 +1265,7 @@ int pcr_render_las(pcr_ctx *c, const pcr_render_params *p)
     c->tiles_tracked = false;        // (this method's kernels do not mark tiles)
     a.level = c->d_las_level; a.win = c->d_las_win; a.stats = c->d_stats; a.win_capacity = WIN_PIXELS;
     c->stats_partials = (int)((nB + PREPASS_THREADS - 1) / PREPASS_THREADS);
+    a.order = c->d_las_order; a.chunk_count = c->d_las_chunk_count; a.chunks = (uint32_t)c->stats_partials;
     hipLaunchKernelGGL(k_las_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
     const bool timed = c->kt_sample_now();
     const int slot = (int)(c->kt_samples % pcr_ctx::KT_PAIRS);

@@ -280,6 +280,12 @@ static int basic_exchange_sliced(pcr_dist *d, const pcr_render_params *p, int ro
 
 int pcr_dist_rank(const pcr_dist *d) { return d ? d->rank : -1; }
 int pcr_dist_world(const pcr_dist *d) { return d ? d->world : 0; }
+int pcr_dist_comm_ranks(const pcr_dist *d)
+{
+    if (!d || !d->comm) return 0;
+    int n = 0;
+    return ncclCommCount(d->comm, &n) == ncclSuccess ? n : -1;
+}
 
 int pcr_dist_group_begin(void) { NCCL_TRY(ncclGroupStart()); return PCR_OK; }
 int pcr_dist_group_end(void) { NCCL_TRY(ncclGroupEnd()); return PCR_OK; }

@@ -1480,7 +1480,16 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     uint32_t e1_ahead = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff1_ahead);
     // DECODE_AHEAD (point windows, basic / depth pass): all three entries of a point are requested during the iteration before
     // it, spread over that iteration (see the loop); these are the ones of point 0
+    // Packed words (round 4): the same order. A point's view is cut from the chain's word queue once the lengths of the point before
+    // it are known -- at the top of the iteration, where all three of its entries have arrived -- so the queue advances THERE,
+    // the words it needs were requested a whole iteration earlier, and the three entries of point i+1 are requested from the new
+    // view during iteration i exactly as with the point windows (round 3's form, kept behind PCR_EXP_WORDS_SERIAL for A/B: every
+    // table read of a point hung on the one before it, two round trips per point exposed).
+#ifdef PCR_EXP_WORDS_SERIAL
     constexpr bool DECODE_AHEAD = LAYOUT == LAYOUT_POINT_WINDOWS;
+#else
+    constexpr bool DECODE_AHEAD = true;
+#endif
     uint32_t toff2_ahead = 0, e2_ahead = 0;
     if (DECODE_AHEAD) {
         toff2_ahead = (uint32_t)(bits >> ((sft_ahead - e1_ahead) & 63u)) & 0x3FFCu;
@@ -1526,6 +1535,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     auto table_entry = [&](uint32_t toff) __attribute__((always_inline)) -> uint32_t {
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_table) + toff);
     };
+    // DECODE_AHEAD, top of iteration i (the entries e0..e2 of point i have arrived): request the first entry of point i+1. Point
+    // windows: its key is the top of the window that has been in registers for an iteration. Packed words: the queue advances by
+    // what point i consumed (the three lengths: byte 0 of the entries, subtracted whole -- only the low six bits of `sft` count),
+    // the view of point i+1 is cut, its top twelve bits are the key. (A macro, not a lambda: a closure that captures the word queue
+    // by reference put the kernel's whole parameter block into scratch memory.)
+#define PCR_NEXT_FIRST_ENTRY(e0_, e1_, e2_)                                                 \
+    do {                                                                                    \
+        if (LAYOUT == LAYOUT_POINT_WINDOWS) {                                               \
+            toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;                               \
+        } else {                                                                            \
+            sft = SFT0 - (e0_) - (e1_) - (e2_);                                             \
+            PCR_ADVANCE_WORD_WINDOW();                                                      \
+            toff_ahead = ((uint32_t)(bits >> 32) >> (SFT0 & 31u)) & 0x3FFCu;                \
+        }                                                                                   \
+        e_ahead = table_entry(toff_ahead);                                                  \
+    } while (0)
     // LAYOUT_WORDS: the symbols of a point AND the first symbol of the next one are cut from one 64-bit view, so every
     // table read hangs on the one before it. esc_first (the third symbol's form): the escape word, if any, is requested
     // BEFORE the next table entry. LDS results return in issue order, so its value can be waited for (lgkmcnt(1)) while the
@@ -1637,8 +1662,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc0), 1)) v0 = *esc_next++;               // :438 (every such entry is an escape whose word is in the pool)
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc1), 1)) v1 = *esc_next++;
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(esc2), 1)) v2 = *esc_next++;
-                toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
-                e_ahead = table_entry(toff_ahead);
+                PCR_NEXT_FIRST_ENTRY(e0, e1, e2);
                 if (COLOR_PASS) {
                     if (__builtin_amdgcn_inverse_ballot_w64(draw)) accumulate(__builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, i - 1);
                 } else if (__builtin_amdgcn_inverse_ballot_w64(draw)) {                         // second half of rasterize() for point i-1
@@ -1651,8 +1675,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
                 d0 = entry_value(e0, toff0);                                    // :430
                 d1 = entry_value(e1, toff1);
                 d2 = entry_value(e2, toff2);
-                toff_ahead = (nwin_hi >> (SFT0 & 31u)) & 0x3FFCu;
-                e_ahead = table_entry(toff_ahead);
+                PCR_NEXT_FIRST_ENTRY(e0, e1, e2);
                 if (COLOR_PASS) scatter(__builtin_amdgcn_inverse_ballot_w64(pend_valid_mask), __builtin_amdgcn_inverse_ballot_w64(pend_off_mask), pend_pix, pend_w, nullptr, pend_depth, pend_old, i - 1);
                 else scatter_min(pend_p, pend_depth, pend_old_hi, pend_off_mask, pend_pix, i - 1);
             }
@@ -1689,7 +1712,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
         px = (int32_t)((uint32_t)px + d0);                                  // :454-456, :463
         py = (int32_t)((uint32_t)py + d1);
         pz = (int32_t)((uint32_t)pz + d2);
-        PCR_ADVANCE_WORD_WINDOW();
+        if (!(DECODE_AHEAD && LAYOUT == LAYOUT_WORDS)) PCR_ADVANCE_WORD_WINDOW();     // (packed words, decode ahead: the queue advanced at the top)
 #ifdef PCR_EXP_NO_RASTER   /* experiment only: decode cost alone (results are wrong) */
         if ((px ^ py ^ pz) == 0x7fffffff && i == 63) g_fb[tid] = 0;
         if (LAYOUT == LAYOUT_POINT_WINDOWS) { nwin_hi = fetched_hi; nwin_lo = fetched_lo << 24; }
@@ -1914,10 +1937,26 @@ struct LasArgs {
     uint2 *win;               // [nB]
     pcr_render_stats *stats;
     int win_capacity;
+    // dense list of the batches k_las_render draws (not culled, not the last one), compacted by the prepass per workgroup of
+    // LAS_PREPASS_BATCHES batches in the file's order, as the Huffman methods' lists are (RenderArgs::order): order[wg * 256 ..],
+    // chunk_count[wg]; k_las_render's workgroup x finds the x-th entry with a wave-wide prefix sum over the chunk counts
+    uint32_t *order;          // [chunks * LAS_PREPASS_BATCHES]
+    uint32_t *chunk_count;    // [LAS_CLASSES][chunks]
+    uint32_t chunks;
 };
+constexpr int LAS_PREPASS_BATCHES = PREPASS_THREADS;     // one lane per batch
+// Heaviest first, as the Huffman lists' classes (RenderArgs::work_classes): class 0 = batches whose screen rectangle the LDS window does
+// not hold (a batch of a tile-ordered cloud that straddles the end of one row of tiles and the start of the next: every point then
+// goes through a global pre-read and a global atomic, 4-6 x the time of a batch with a window -- a few dozen of them in a frame, and
+// drawn where the file has them they end the launch alone on their CUs: 0.23 ms where the wave lifetimes sum to 0.11), class 1 = the rest.
+// A chunk's records are stored class after class, chunk_count[class][chunk] counts them.
+constexpr int LAS_CLASSES = 2;
 
-__device__ __forceinline__ uint2 window_rect(const pcr_render_params &p, const float *bmin, const float *bmax, int capacity)
+// (*partial: the rectangle had to be cut down to the capacity, or the batch gets no window at all although it is on screen -- its
+// points, or many of them, take the global path)
+__device__ __forceinline__ uint2 window_rect(const pcr_render_params &p, const float *bmin, const float *bmax, int capacity, bool *partial = nullptr)
 {
+    if (partial) *partial = true;
     float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
     const float fw = (float)p.width, fh = (float)p.height;
     for (int c = 0; c < 8; ++c) {
@@ -1932,6 +1971,7 @@ __device__ __forceinline__ uint2 window_rect(const pcr_render_params &p, const f
     int x0 = max(0, (int)floorf(fmaxf(minx, -2.0f)) - 1), x1 = min(p.width - 1, (int)floorf(fminf(maxx, fw + 2.0f)) + 1);
     int y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1), y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
     int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+    if (partial && ww > 0 && wh > 0 && (int64_t)ww * wh <= capacity) *partial = false;      // the whole rectangle fits
     if (ww > 0 && wh > 0 && (int64_t)ww * wh > capacity && (int64_t)ww * wh <= 16 * (int64_t)capacity) {
         const float sc = sqrtf((float)capacity / ((float)ww * (float)wh));
         const int nw = max(1, (int)floorf((float)ww * sc)), nh = max(1, (int)floorf((float)wh * sc));
@@ -1942,17 +1982,43 @@ __device__ __forceinline__ uint2 window_rect(const pcr_render_params &p, const f
     return make_uint2(0, 0);
 }
 
-__device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, pcr_render_stats &st);
+__device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, pcr_render_stats &st, bool *heavy);
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_las_prepass(LasArgs a)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     pcr_render_stats st = {0, 0, 0, 0};
-    if (b < a.s.num_batches) las_prepass_batch(a, b, st);
+    uint32_t cls = LAS_CLASSES;                                             // not drawn
+    if (b < a.s.num_batches) {
+        bool heavy = false;
+        las_prepass_batch(a, b, st, &heavy);
+        if (a.level[b] >= 0 && b != a.s.num_batches - 1) cls = heavy ? 0u : 1u;      // render.cu:153-155, :201-202
+    }
     commit_stats(st, a.stats);
+    // compaction of the batches to draw, order preserving inside a class: a ballot per wave and class, the waves' counts through LDS
+    __shared__ uint32_t s_wave_count[LAS_CLASSES][PREPASS_THREADS / 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint64_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)LAS_CLASSES; ++k) {
+        const uint64_t m = __ballot(cls == k);
+        if (lane == 0) s_wave_count[k][wave] = (uint32_t)__popcll(m);
+        if (cls == k) mine = m;
+    }
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)LAS_CLASSES; ++k) {
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < PREPASS_THREADS / 64; ++w) { if (k == cls && w < wave) base += s_wave_count[k][w]; total += s_wave_count[k][w]; }
+        if (k < cls) base += total;                                         // my chunk's records of the classes in front of mine
+        if (threadIdx.x == 0) a.chunk_count[k * a.chunks + blockIdx.x] = total;
+    }
+    if (cls < (uint32_t)LAS_CLASSES) a.order[(size_t)blockIdx.x * LAS_PREPASS_BATCHES + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = (uint32_t)b;
 }
 
-__device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, pcr_render_stats &st)
+__device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, pcr_render_stats &st, bool *heavy)
 {
     const pcr_xyz_batch g = a.s.batches[b];
     const pcr_render_params &p = a.p;
@@ -1993,108 +2059,200 @@ __device__ __forceinline__ void las_prepass_batch(const LasArgs &a, int64_t b, p
     a.level[b] = px < 100.0f ? 4 : px < 200.0f ? 3 : px < 500.0f ? 2 : px < 10000.0f ? 1 : 0;
     if (b != a.s.num_batches - 1)                                            // the last workgroup returns early (:201-202)
         st.points_iterated += PCR_POINTS_PER_BATCH;
-    a.win[b] = window_rect(p, bmin, bmax, a.win_capacity);
+    a.win[b] = window_rect(p, bmin, bmax, a.win_capacity, heavy);
 }
 
+// Round 4: brought to k_render's standard. The window starts EMPTY (round 1 copied the framebuffer's words into it: a global read
+// of every window pixel in front of the barrier); a point's depth is tested against the depth half of its window word, read a
+// whole point before it is used, and only then is the 64-bit key put together for the ds_min_u64 (round 1: a 64-bit LDS read and
+// compare in front of the atomic, the round trip exposed four times per quad); "inside the frustum" / "inside the window" are
+// lane masks in scalar registers, a lane without a window word reads a dummy slot whose depth 0 turns it away; the merge issues
+// its atomic without reading the pixel first; batches are drawn through the prepass's compacted list. Points outside the window
+// keep their pre-read of the global word (strip-ordered clouds put most points there: unfiltered 8 x the time in atomics), now
+// requested a point ahead like the window word. Reference: modules/compute_loop_las_cuda/render.cu:204-327 (USE_PREFETCH loop),
+// :108-128 (rasterize).
 __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
 {
-    const uint32_t b = blockIdx.x;
+    // which batch is the blockIdx.x-th of the list? (every wave for itself: a 64-lane inclusive prefix sum over the chunk counts)
+    uint32_t b;
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        // Heaviest class first only while it is a minority (a few stragglers among batches with windows: started first, they run beside
+        // everything else). A frame made of such batches (a close-up: every batch larger on screen than its window) is bound by its
+        // global atomics, and drawn class by class it was 18 % slower than in the file's order -- then the chunks are walked in order.
+        uint32_t heavy_total = 0, all_total = 0;
+        for (uint32_t c0 = 0; c0 < a.chunks; c0 += 64) {                    // (uniform)
+            uint32_t h = c0 + lane < a.chunks ? a.chunk_count[c0 + lane] : 0u, l = c0 + lane < a.chunks ? a.chunk_count[a.chunks + c0 + lane] : 0u;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { h += __shfl_xor(h, m); l += __shfl_xor(l, m); }
+            heavy_total += h; all_total += h + l;
+        }
+        const bool by_class = heavy_total * 4u < all_total;
+        static_assert(LAS_CLASSES == 2, "heavy / light");
+        uint32_t x = blockIdx.x, found = 0xFFFFFFFFu;
+        for (uint32_t cls = 0; cls < (by_class ? 2u : 1u) && found == 0xFFFFFFFFu; ++cls) {       // (uniform)
+            uint32_t before = 0;
+            for (uint32_t c0 = 0; c0 < a.chunks; c0 += 64) {                // (uniform)
+                const uint32_t c = c0 + lane;
+                // by class: the chunk's records of this class; in the file's order: all of the chunk's records (heavy ones first inside it)
+                const uint32_t cnt = c < a.chunks ? (by_class ? a.chunk_count[cls * a.chunks + c] : a.chunk_count[c] + a.chunk_count[a.chunks + c]) : 0u;
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d);
+                    if ((int)lane >= d) incl += up;
+                }
+                const uint32_t total = __shfl(incl, 63);
+                if (x < before + total) {
+                    const uint64_t m = __ballot(before + incl > x);
+                    const uint32_t first = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                    const uint32_t excl = __shfl(incl - cnt, first);
+                    const uint32_t lighter = by_class && cls == 1u ? a.chunk_count[c0 + first] : 0u;      // the chunk's heavy records lie in front
+                    found = (c0 + first) * LAS_PREPASS_BATCHES + lighter + (x - before - excl);
+                    break;
+                }
+                before += total;
+            }
+            x -= before;                                                    // (not found: `before` is the class's total)
+        }
+        found = __builtin_amdgcn_readfirstlane(found);
+        if (found == 0xFFFFFFFFu) return;                                   // the grid is sized for "every batch drawn"
+        b = a.order[found];
+    }
     const int level = a.level[b];
-    if (level < 0 || b == (uint32_t)(a.s.num_batches - 1)) return;           // :153-155, :201-202
     const uint32_t tid = threadIdx.x;
-    __shared__ __align__(16) unsigned long long s_win[WIN_PIXELS];
+    __shared__ __align__(16) unsigned long long s_win[WIN_PIXELS + 1];
 
     const uint2 wr = a.win[b];
     const uint32_t wx0 = wr.x & 0xFFFFu, wy0 = wr.x >> 16, ww = wr.y & 0xFFFFu, wh = wr.y >> 16;
     const uint32_t wpix = ww * wh;
     const uint32_t W = (uint32_t)a.p.width;
     const float inv_ww = 1.0f / (float)max(ww, 1u);
-    for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
-        uint32_t y, x;
-        window_row_col(i, ww, inv_ww, y, x);
-        s_win[i] = a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
-    }
+    for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) s_win[i] = ~0ull;
+    if (tid == 0) s_win[wpix] = 0ull;                                        // the dummy slot: depth 0, no point passes it
     const pcr_xyz_batch g = a.s.batches[b];
     const float div = level >= 2 ? 1024.0f : 1073741824.0f;                  // STEPS_10BIT / STEPS_30BIT
     const float sx = (g.max_x - g.min_x) / div, sy = (g.max_y - g.min_y) / div, sz = (g.max_z - g.min_z) / div;   // :145, :345
+    // (the w row of the matrix in vector registers, as in k_render: a v_fma_f32 whose operands are all VGPRs issues in ~2.3 cycles,
+    // with an SGPR operand in ~4.2; the x and y rows run as packed operations with scalar pairs)
+    auto in_vgpr = [](float v) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     const float *M = a.p.transform;
+    const float m00 = M[0], m01 = M[1], m02 = M[2], m03 = M[3];
+    const float m10 = M[4], m11 = M[5], m12 = M[6], m13 = M[7];
+    const float m30 = in_vgpr(M[12]), m31 = in_vgpr(M[13]), m32 = in_vgpr(M[14]), m33 = in_vgpr(M[15]);
+    const float vsx = sx, vsy = sy, vsz = sz, vox = g.min_x, voy = g.min_y, voz = g.min_z;
     const float fw = (float)a.p.width, fh = (float)a.p.height;
+    const int img_w = a.p.width;
+    uint64_t *const g_fb = a.f.fb;
     const size_t base = (size_t)b * PCR_POINTS_PER_BATCH;
     const uint4 *q4 = reinterpret_cast<const uint4 *>(a.s.xyz4 + base);
     const uint4 *q8 = reinterpret_cast<const uint4 *>(a.s.xyz8 + base);
     const uint4 *q12 = reinterpret_cast<const uint4 *>(a.s.xyz12 + base);
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    lds_u64 *const s_w = (lds_u64 *)s_win;
+    // the pending point: projected, its window word's depth half requested; scattered while the next point is projected
+    lds_u64 *pend_p = s_w + wpix;
+    uint32_t pend_depth = 0, pend_old_hi = 0, pend_index = 0, pend_pix = 0;
+    uint64_t pend_off_mask = 0;                                              // lanes whose pending point is inside the frustum but outside the window
     __syncthreads();
 
-    uint4 n4 = q4[tid], n8 = make_uint4(0, 0, 0, 0), n12 = make_uint4(0, 0, 0, 0);
-    if (level <= 1) n8 = q8[tid];
-    if (level == 0) n12 = q12[tid];
-    for (int i = 0; i < PCR_POINTS_PER_BATCH / 4 / PCR_WORKGROUP_SIZE; ++i) {
-        const uint4 c4 = n4, c8 = n8, c12 = n12;
-        const uint32_t quad = tid + (uint32_t)i * PCR_WORKGROUP_SIZE;
-        if (i + 1 < PCR_POINTS_PER_BATCH / 4 / PCR_WORKGROUP_SIZE) {         // next quad in flight while this one is projected
-            n4 = q4[quad + PCR_WORKGROUP_SIZE];
-            if (level <= 1) n8 = q8[quad + PCR_WORKGROUP_SIZE];
-            if (level == 0) n12 = q12[quad + PCR_WORKGROUP_SIZE];
+    auto scatter_pending = [&]() __attribute__((always_inline)) {
+        // rasterize, second half (:119-126): the pre-read filter on the depth half, then the min (ties go to the atomic: min is idempotent)
+        if (pend_depth <= pend_old_hi) {
+            const unsigned long long key = ((unsigned long long)pend_depth << 32) | pend_index;             // :119-120
+            // (either / or: in a strip-ordered cloud most lanes are outside the window, and 50 of them on the dummy slot's one
+            // address would serialise the LDS atomic)
+            if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) atomicMin((unsigned long long *)&g_fb[pend_pix], key);   // :123-126
+            else __hip_atomic_fetch_min(pend_p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const uint32_t w4[4] = { c4.x, c4.y, c4.z, c4.w }, w8[4] = { c8.x, c8.y, c8.z, c8.w }, w12[4] = { c12.x, c12.y, c12.z, c12.w };
+    };
+    auto point = [&](uint32_t X, uint32_t Y, uint32_t Z, uint32_t index) __attribute__((always_inline)) {
+        const float x = __fmaf_rn((float)X, vsx, vox), y = __fmaf_rn((float)Y, vsy, voy), z = __fmaf_rn((float)Z, vsz, voz);
+        // rasterize, first half (:108-118); projection as in k_render (exact inside test without dividing, shared-reciprocal division)
+        const float qx = __fmaf_rn(m03, 1.0f, __fmaf_rn(m02, z, __fmaf_rn(m01, y, m00 * x)));
+        const float qy = __fmaf_rn(m13, 1.0f, __fmaf_rn(m12, z, __fmaf_rn(m11, y, m10 * x)));
+        const float qw = __fmaf_rn(m33, 1.0f, __fmaf_rn(m32, z, __fmaf_rn(m31, y, m30 * x)));
+        const uint64_t cand_mask = __builtin_amdgcn_ballot_w64(fabsf(qx) <= qw) & __builtin_amdgcn_ballot_w64(fabsf(qy) <= qw);
+        int ix, iy;
+        {
+            const float r0 = __builtin_amdgcn_rcpf(qw);
+            const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
+            const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
+            const v2f q0 = xy * rr;
+            const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
+            const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
+            const v2f half = {0.5f, 0.5f}, size = {fw, fh};
+            const v2f img = __builtin_elementwise_fma(q2, half, half) * size;
+            ix = (int)img.x; iy = (int)img.y;
+        }
+        const uint64_t w_ok_mask = __builtin_amdgcn_ballot_w64((__float_as_uint(qw) - 0x1F800000u) < 0x40000000u);   // 2^-64 <= w < 2^64
+        if (__builtin_expect((cand_mask & ~w_ok_mask) != 0, 0)) {           // (uniform, practically never) the plain `/` for all lanes
+            const float nx = qx / qw, ny = qy / qw;
+            ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);
+            iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+        }
+        scatter_pending();                                                   // the point before this one: its window word has arrived by now
+        const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
+        const uint64_t in_mask = cand_mask & __builtin_amdgcn_ballot_w64(rx < ww) & __builtin_amdgcn_ballot_w64(ry < wh);
+        pend_off_mask = cand_mask & ~in_mask;
+        pend_depth = __float_as_uint(qw);
+        pend_index = index;
+        pend_p = s_w + (__builtin_amdgcn_inverse_ballot_w64(in_mask) ? (uint32_t)__umul24(ry, ww) + rx : wpix);
+        pend_old_hi = reinterpret_cast<__attribute__((address_space(3))) const uint32_t *>(pend_p)[1];
+        if (__builtin_expect(pend_off_mask != 0, 0)) {                      // (uniform) some lane's point lies outside the window: the global word's depth (:123)
+            if (__builtin_amdgcn_inverse_ballot_w64(pend_off_mask)) {
+                pend_pix = (uint32_t)(ix + iy * img_w);
+                // (consumed inside the branch: no load is pending where the paths join, so hipcc's waits for the next quad's words,
+                // requested a whole quad ahead, stay counted instead of becoming vmcnt(0) in front of every scatter)
+                uint32_t seen = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&g_fb[pend_pix]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                asm volatile("; framebuffer word of a point outside its window %0" : "+v"(seen));
+                pend_old_hi = seen;
+            }
+        }
+    };
+
+    // One copy of the loop per number of level arrays read (4 / 8 / 12 bytes per point): the copy that reads one array does not
+    // carry the registers of the other two (with one loop for all three, the 64-register budget of eight waves per SIMD spilled).
+    auto quads = [&](auto arrays_) __attribute__((always_inline)) {
+        constexpr int ARRAYS = decltype(arrays_)::value;
+        uint4 n4 = q4[tid], n8 = make_uint4(0, 0, 0, 0), n12 = make_uint4(0, 0, 0, 0);
+        if (ARRAYS >= 2) n8 = q8[tid];
+        if (ARRAYS >= 3) n12 = q12[tid];
+#pragma unroll 1
+        for (int i = 0; i < PCR_POINTS_PER_BATCH / 4 / PCR_WORKGROUP_SIZE; ++i) {
+            const uint4 c4 = n4, c8 = n8, c12 = n12;
+            const uint32_t quad = tid + (uint32_t)i * PCR_WORKGROUP_SIZE;
+            {   // next quad in flight while this one is projected (the last iteration re-reads its own: no branch around the loads)
+                const uint32_t nq = min(quad + PCR_WORKGROUP_SIZE, (uint32_t)(PCR_POINTS_PER_BATCH / 4 - 1));
+                n4 = q4[nq];
+                if (ARRAYS >= 2) n8 = q8[nq];
+                if (ARRAYS >= 3) n12 = q12[nq];
+            }
+            const uint32_t w4[4] = { c4.x, c4.y, c4.z, c4.w }, w8[4] = { c8.x, c8.y, c8.z, c8.w }, w12[4] = { c12.x, c12.y, c12.z, c12.w };
+            const uint32_t index0 = (uint32_t)base + quad * 4;
+            if (ARRAYS == 1) {                                                   // :381-392 (levels 2..4)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t index = (uint32_t)base + quad * 4 + j;
-            uint32_t X, Y, Z;
-            if (level >= 2) {                                                // :381-392
-                X = w4[j] & 1023u; Y = (w4[j] >> 10) & 1023u; Z = (w4[j] >> 20) & 1023u;
-            } else {                                                         // :333-378
-                X = ((w4[j] & 1023u) << 20) | ((w8[j] & 1023u) << 10) | (w12[j] & 1023u);
-                Y = (((w4[j] >> 10) & 1023u) << 20) | (((w8[j] >> 10) & 1023u) << 10) | ((w12[j] >> 10) & 1023u);
-                Z = (((w4[j] >> 20) & 1023u) << 20) | (((w8[j] >> 20) & 1023u) << 10) | ((w12[j] >> 20) & 1023u);
-            }
-            const float x = __fmaf_rn((float)X, sx, g.min_x), y = __fmaf_rn((float)Y, sy, g.min_y), z = __fmaf_rn((float)Z, sz, g.min_z);
-            // rasterize (:108-128); projection as in k_render (exact inside test, shared-reciprocal division)
-            const float qx = dot4(M + 0, x, y, z, 1.0f), qy = dot4(M + 4, x, y, z, 1.0f), qw = dot4(M + 12, x, y, z, 1.0f);
-            uint32_t pix = NO_PIXEL;
-            int ix = 0, iy = 0;
-            const bool w_ok = (__float_as_uint(qw) - 0x1F800000u) < 0x40000000u;
-            if (__builtin_expect(__any(!w_ok && !(qw <= 0.0f)), 0)) {
-                const float nx = qx / qw, ny = qy / qw;
-                if (qw > 0.0f && nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) {
-                    ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw); iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
-                    pix = (uint32_t)(ix + iy * a.p.width);
-                    if (pix >= a.f.fb_elems) pix = NO_PIXEL;
-                }
-            } else if (w_ok && fabsf(qx) <= qw && fabsf(qy) <= qw) {
-                const float r0 = __builtin_amdgcn_rcpf(qw);
-                const float r1 = __fmaf_rn(__fmaf_rn(-qw, r0, 1.0f), r0, r0);
-                const v2f xy = {qx, qy}, rr = {r1, r1}, nw = {-qw, -qw};
-                const v2f q0 = xy * rr;
-                const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q0, xy), rr, q0);
-                const v2f q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, q1, xy), rr, q1);
-                const v2f half = {0.5f, 0.5f}, size = {fw, fh};
-                const v2f img = __builtin_elementwise_fma(q2, half, half) * size;
-                ix = (int)img.x; iy = (int)img.y;
-                pix = (uint32_t)(ix + iy * a.p.width);
-            }
-            if (pix != NO_PIXEL) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(qw) << 32) | index;   // :119-120
-                const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;
-                if (rx < ww && ry < wh) {
-                    const uint32_t widx = ry * ww + rx;
-                    if (key < s_win[widx]) __hip_atomic_fetch_min(&s_win[widx], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (key < a.f.fb[pix]) {                              // :123-126
-                    // (kept here, unlike in k_render: strip-ordered clouds put most points outside the window, and unfiltered they
-                    // cost 8 x the time in atomics -- 0.365 -> 2.94 ms; tile-ordered 0.248 -> 0.478; only the close-up gained)
-                    atomicMin((unsigned long long *)&a.f.fb[pix], key);
-                }
+                for (int j = 0; j < 4; ++j) point(w4[j] & 1023u, (w4[j] >> 10) & 1023u, (w4[j] >> 20) & 1023u, index0 + j);
+            } else {                                                             // :333-378 (level 1: the 12-byte array's bits are zero)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    point(((w4[j] & 1023u) << 20) | ((w8[j] & 1023u) << 10) | (w12[j] & 1023u),
+                          (((w4[j] >> 10) & 1023u) << 20) | (((w8[j] >> 10) & 1023u) << 10) | ((w12[j] >> 10) & 1023u),
+                          (((w4[j] >> 20) & 1023u) << 20) | (((w8[j] >> 20) & 1023u) << 10) | ((w12[j] >> 20) & 1023u), index0 + j);
             }
         }
-    }
+    };
+    if (level >= 2)      quads(std::integral_constant<int, 1>{});
+    else if (level == 1) quads(std::integral_constant<int, 2>{});
+    else                 quads(std::integral_constant<int, 3>{});
+    scatter_pending();
     if (wpix) {
         __syncthreads();
         for (uint32_t i = tid; i < wpix; i += PCR_WORKGROUP_SIZE) {
             uint32_t y, x;
             window_row_col(i, ww, inv_ww, y, x);
             const unsigned long long v = s_win[i];
-            unsigned long long *gp = (unsigned long long *)&a.f.fb[(size_t)(wy0 + y) * W + wx0 + x];
-            if (v < *gp) atomicMin(gp, v);                      // (unfiltered, as in k_render's merge: no difference here, +-1 %)
+            if (v != ~0ull) atomicMin((unsigned long long *)&a.f.fb[(size_t)(wy0 + y) * W + wx0 + x], v);      // (a pixel no point reached issues nothing)
         }
     }
 }

@@ -334,11 +334,16 @@ class NativeDist:
         """render + merge + (resolve, clear, next prepass in one launch); prime with ctx.frame_begin(params) once."""
         self._chk(self.lib.pcr_dist_step_basic(self.h, self._C.byref(params), root), "pcr_dist_step_basic")
 
+    def comm_ranks(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
+        self.lib.pcr_dist_comm_ranks.argtypes = [self._C.c_void_p]
+        return int(self.lib.pcr_dist_comm_ranks(self.h))
+
     EXCHANGE = {"auto": 0, "reduce": 1, "sliced": 2, "sliced_p2p": 3}
 
     def set_exchange(self, mode: str) -> str:
         """Which exchange the frame calls use (include/pcr_dist.h: PCR_DIST_EXCHANGE_*); returns what it resolves to for the
-        context's image size ("auto": sliced from 64 MB frames on)."""
+        context's image size ("auto" = reduce until the sliced forms have met a peer on hardware)."""
         self._chk(self.lib.pcr_dist_set_exchange(self.h, self.EXCHANGE[mode]), "pcr_dist_set_exchange")
         got = self.lib.pcr_dist_exchange(self.h)
         return {v: k for k, v in self.EXCHANGE.items()}[got]

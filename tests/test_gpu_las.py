@@ -164,3 +164,26 @@ def test_las_random_cameras(renderer, cloud):
         _check(renderer.ctx, q, p)
         levels |= {oracle.las_level(q[0][b], p) for b in range(len(q[0]))}
     assert {0, 1, 2} <= levels
+
+
+def test_las_several_chunks_of_the_draw_list():
+    """More than 256 batches (two chunks of the prepass's compacted list), a tile-ordered cloud whose batches straddle the ends of the
+    tile rows: a few heavy batches among light ones (drawn heaviest class first), a close-up where every batch is heavy (drawn in the
+    file's order), culling on and off -- against the oracle."""
+    total = 300 * PPB + 123
+    x, y, z, c = P.synth_points(total, scenes.SEED, 0, total)
+    las = P.synth_las_info(total, scenes.SEED)
+    side = 57_000                                # ~65 536 points per square tile of the 1e6-unit scene at this density
+    idx = np.argsort((y // side).astype(np.int64) * 4096 + x // side, kind="stable")
+    pts = (x[idx], y[idx], z[idx], c[idx], las)
+    q = P.las_quantize(*pts)
+    assert len(q[0]) == 301
+    r = P.Renderer(1920, 1080, device=0)
+    try:
+        _load(r, pts)
+        for cam in ("overview", "closeup"):
+            for cull in (0, 1):
+                st = _check(r.ctx, q, scenes.with_flags(scenes.cameras(1920, 1080)[cam], cull=cull))
+                assert st["batches_total"] == 301
+    finally:
+        r.ctx.close()
