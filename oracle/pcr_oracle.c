@@ -360,6 +360,7 @@ typedef struct {
     uint64_t *rg, *ba;
     uint32_t *tie;               /* MODE_TIE_COUNT: per pixel, bits 30:0 = points at the winning depth, bit 31 = one of them has another colour */
     size_t fb_elems;
+    int shared_fb;               /* several host threads draw into fb (the multi-threaded CPU baseline): atomic min */
 } raster_ctx;
 
 static void sink_raster(void *vctx, int chain, int i, int32_t cx, int32_t cy, int32_t cz)
@@ -426,7 +427,7 @@ static void sink_raster(void *vctx, int chain, int i, int32_t cx, int32_t cy, in
          * points of depth<<32|colour: the reference's non-atomic pre-read filter
          * (:297-298) only prunes candidates that cannot win, except at exact depth ties. */
         uint64_t hi = (uint64_t)depth << 32;
-        if (hi > (c->fb[pix] | 0xFFFFFFFFull)) return;
+        if (hi > (__atomic_load_n(&c->fb[pix], __ATOMIC_RELAXED) | 0xFFFFFFFFull)) return;
         key = hi | pcr_oracle_decode_bc1(index, c->s->colors);       /* :299 */
     } else {
         uint32_t payload = 0;                                                               /* hqs depth.cu:144 */
@@ -434,16 +435,22 @@ static void sink_raster(void *vctx, int chain, int i, int32_t cx, int32_t cy, in
         else if (p->colorize_chunks) payload = (uint32_t)(c->s->batch_index_base + c->batch); /* :141-142 blockIdx.x */
         key = ((uint64_t)depth << 32) | payload;
     }
-    if (key < c->fb[pix]) c->fb[pix] = key;                           /* :300 atomicMin */
+    if (!c->shared_fb) {
+        if (key < c->fb[pix]) c->fb[pix] = key;                       /* :300 atomicMin */
+    } else {
+        /* several host threads draw into ONE framebuffer (pcr_oracle_render_basic_mt): the same atomicMin as a compare-exchange loop */
+        uint64_t old = __atomic_load_n(&c->fb[pix], __ATOMIC_RELAXED);
+        while (key < old && !__atomic_compare_exchange_n(&c->fb[pix], &old, key, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+    }
 }
 
-static void render_range(const pcr_oracle_stream *s, const pcr_render_params *p, int mode,
-                         int64_t first, int64_t count, uint64_t *fb, uint64_t *rg, uint64_t *ba,
-                         pcr_render_stats *stats)
+static void render_range_ex(const pcr_oracle_stream *s, const pcr_render_params *p, int mode,
+                            int64_t first, int64_t count, uint64_t *fb, uint64_t *rg, uint64_t *ba,
+                            pcr_render_stats *stats, int shared_fb)
 {
     raster_ctx c;
     memset(&c, 0, sizeof c);
-    c.s = s; c.p = p; c.mode = mode; c.fb = fb; c.rg = rg; c.ba = ba;
+    c.s = s; c.p = p; c.mode = mode; c.fb = fb; c.rg = rg; c.ba = ba; c.shared_fb = shared_fb;
     c.fb_elems = pcr_fb_elems(p->width, p->height);
     for (int64_t bi = first; bi < first + count; ++bi) {
         const pcr_gpu_batch *b = &s->batches[bi];
@@ -466,6 +473,13 @@ static void render_range(const pcr_oracle_stream *s, const pcr_render_params *p,
         for (int k = 0; k < 3; ++k) { c.scalef[k] = (float)c.scale[k]; c.offf[k] = (float)c.offd[k]; }
         for (int cl = 0; cl < 32; ++cl) decode_cluster(s, bi, cl, npr, sink_raster, &c);
     }
+}
+
+static void render_range(const pcr_oracle_stream *s, const pcr_render_params *p, int mode,
+                         int64_t first, int64_t count, uint64_t *fb, uint64_t *rg, uint64_t *ba,
+                         pcr_render_stats *stats)
+{
+    render_range_ex(s, p, mode, first, count, fb, rg, ba, stats, 0);
 }
 
 void pcr_oracle_render_basic(const pcr_oracle_stream *s, const pcr_render_params *p,
@@ -523,44 +537,26 @@ int pcr_oracle_count_depth_ties(const pcr_oracle_stream *s, const pcr_render_par
     return 0;
 }
 
-/* Multi-threaded basic render for the CPU baseline: batches handed out one at a time (an atomic counter), a
- * framebuffer per thread that the thread itself clears, then every thread min-merges its share of the pixels over all the
- * buffers -- nothing serial left but thread creation, so that the row "all host cores" of bench.py (256 on the GPU box) measures the
- * render and not a 4 GB memset by one core. min is associative and commutative: the frame does not depend on who drew what. */
+/* Multi-threaded basic render for the CPU baseline: batches handed out one at a time (an atomic counter), ONE
+ * framebuffer that every thread draws into with the CPU form of the kernels' atomicMin (a compare-exchange loop behind the same
+ * pre-read filter, rasterize() above). min is associative and commutative: the frame does not depend on who drew what, nor when.
+ * (Round 3 gave every thread a framebuffer of its own and merged them: at 256 threads that is 4 GB of page faults and a merge
+ * for 10 ms of rendering per thread -- the row "all host cores" of bench.py measured the allocator.) */
 typedef struct {
     const pcr_oracle_stream *s; const pcr_render_params *p;
-    int64_t first, count; int nthreads; size_t n;
-    uint64_t **fbs; int64_t next; pthread_barrier_t bar; int failed;
+    int64_t first, count; uint64_t *fb; int64_t next;
 } mt_shared;
-typedef struct { mt_shared *sh; int tid; pcr_render_stats stats; } mt_job;
+typedef struct { mt_shared *sh; pcr_render_stats stats; } mt_job;
 
 static void *mt_worker(void *arg)
 {
     mt_job *j = (mt_job *)arg;
     mt_shared *sh = j->sh;
-    uint64_t *fb = sh->fbs[j->tid];
-    if (j->tid) {
-        fb = (uint64_t *)malloc(sh->n * 8);
-        if (fb) memset(fb, 0xFF, sh->n * 8); else __atomic_store_n(&sh->failed, 1, __ATOMIC_RELAXED);
-        sh->fbs[j->tid] = fb;
+    for (;;) {
+        const int64_t b = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
+        if (b >= sh->count) break;
+        render_range_ex(sh->s, sh->p, MODE_BASIC, sh->first + b, 1, sh->fb, NULL, NULL, &j->stats, 1);
     }
-    if (fb)
-        for (;;) {
-            const int64_t b = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
-            if (b >= sh->count) break;
-            render_range(sh->s, sh->p, MODE_BASIC, sh->first + b, 1, fb, NULL, NULL, &j->stats);
-        }
-    pthread_barrier_wait(&sh->bar);
-    /* my share of the pixels, over every thread's buffer */
-    const size_t lo = sh->n * (size_t)j->tid / (size_t)sh->nthreads, hi = sh->n * ((size_t)j->tid + 1) / (size_t)sh->nthreads;
-    uint64_t *out = sh->fbs[0];
-    for (int t = 1; t < sh->nthreads; ++t) {
-        const uint64_t *src = sh->fbs[t];
-        if (!src) continue;
-        for (size_t i = lo; i < hi; ++i) if (src[i] < out[i]) out[i] = src[i];
-    }
-    pthread_barrier_wait(&sh->bar);
-    if (j->tid) free(fb);
     return NULL;
 }
 
@@ -572,24 +568,19 @@ int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_para
     if ((int64_t)nthreads > count && count > 0) nthreads = (int)count;
     mt_shared sh;
     memset(&sh, 0, sizeof sh);
-    sh.s = s; sh.p = p; sh.first = first; sh.count = count; sh.nthreads = nthreads; sh.n = pcr_fb_elems(p->width, p->height);
-    sh.fbs = (uint64_t **)calloc((size_t)nthreads, sizeof *sh.fbs);
+    sh.s = s; sh.p = p; sh.first = first; sh.count = count; sh.fb = fb;
     mt_job *jobs = (mt_job *)calloc((size_t)nthreads, sizeof *jobs);
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
-    if (!sh.fbs || !jobs || !th || pthread_barrier_init(&sh.bar, NULL, (unsigned)nthreads)) { free(sh.fbs); free(jobs); free(th); return -1; }
-    sh.fbs[0] = fb;
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
     int started = 0;
     for (int t = 0; t < nthreads; ++t) {
-        jobs[t].sh = &sh; jobs[t].tid = t;
-        if (pthread_create(&th[t], NULL, mt_worker, &jobs[t])) break;
+        jobs[t].sh = &sh;
+        if (pthread_create(&th[t], NULL, mt_worker, &jobs[t])) break;       /* (fewer threads draw the same frame) */
         ++started;
     }
-    if (started != nthreads) {      /* (the barrier would never open: a box that refuses threads is not one to take a baseline on) */
-        fprintf(stderr, "pcr_oracle_render_basic_mt: only %d of %d threads could be started\n", started, nthreads);
-        abort();
-    }
-    for (int t = 0; t < nthreads; ++t) {
-        pthread_join(th[t], NULL);
+    if (!started) mt_worker(&jobs[0]);
+    for (int t = 0; t < (started ? started : 1); ++t) {
+        if (started) pthread_join(th[t], NULL);
         if (stats) {
             stats->batches_total += jobs[t].stats.batches_total;
             stats->batches_culled += jobs[t].stats.batches_culled;
@@ -597,10 +588,8 @@ int pcr_oracle_render_basic_mt(const pcr_oracle_stream *s, const pcr_render_para
             stats->batches_double += jobs[t].stats.batches_double;
         }
     }
-    const int failed = sh.failed;
-    pthread_barrier_destroy(&sh.bar);
-    free(sh.fbs); free(jobs); free(th);
-    return failed ? -1 : 0;
+    free(jobs); free(th);
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -238,6 +238,24 @@ struct RenderArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
+// wave64 inclusive prefix sum in six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast 15 / 31 across
+// them): no LDS, no wait. (__shfl_up compiles to ds_bpermute_b32: the scans at the top of k_render -- one per class of the list,
+// every wave for itself -- were seven dependent LDS round trips each, ~1 us of a workgroup's set-up per class.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1 (lanes without a source add 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// value of lane `lane` (uniform), as a scalar
+__device__ __forceinline__ uint32_t wave_read_lane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+// ------------------------------------------------------------------------------------------------
 // strict-float helpers (helper_math.h semantics, Appendix C.1)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dot4(const float *r, float x, float y, float z, float w)
@@ -1111,17 +1129,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
             uint32_t before = 0;
             for (uint32_t c0 = 0; c0 < chunks; c0 += 64) {                  // (uniform)
                 const uint32_t cnt = c0 + lane < chunks ? cc[c0 + lane] : 0u;
-                uint32_t incl = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(incl, d);
-                    if ((int)lane >= d) incl += up;
-                }
-                const uint32_t total = __shfl(incl, 63);
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                const uint32_t total = wave_read_lane(incl, 63);
                 if (x < before + total) {
                     const uint64_t m = __ballot(before + incl > x);        // first chunk whose inclusive count passes x
                     const uint32_t first = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-                    const uint32_t excl = __shfl(incl - cnt, first);
+                    const uint32_t excl = wave_read_lane(incl - cnt, first);
                     uint32_t lighter = 0;                                   // the chunk's records of the classes in front of this one
                     for (uint32_t k = 0; k < cls; ++k) lighter += a.chunk_count[k * PCR_MAX_PREPASS_WORKGROUPS + c0 + first];
                     found = (c0 + first) * PREPASS_BATCHES + lighter + (x - before - excl);
@@ -2083,8 +2096,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
         uint32_t heavy_total = 0, all_total = 0;
         for (uint32_t c0 = 0; c0 < a.chunks; c0 += 64) {                    // (uniform)
             uint32_t h = c0 + lane < a.chunks ? a.chunk_count[c0 + lane] : 0u, l = c0 + lane < a.chunks ? a.chunk_count[a.chunks + c0 + lane] : 0u;
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) { h += __shfl_xor(h, m); l += __shfl_xor(l, m); }
+            h = wave_read_lane(wave_inclusive_sum(h), 63); l = wave_read_lane(wave_inclusive_sum(l), 63);
             heavy_total += h; all_total += h + l;
         }
         const bool by_class = heavy_total * 4u < all_total;
@@ -2096,17 +2108,12 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
                 const uint32_t c = c0 + lane;
                 // by class: the chunk's records of this class; in the file's order: all of the chunk's records (heavy ones first inside it)
                 const uint32_t cnt = c < a.chunks ? (by_class ? a.chunk_count[cls * a.chunks + c] : a.chunk_count[c] + a.chunk_count[a.chunks + c]) : 0u;
-                uint32_t incl = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(incl, d);
-                    if ((int)lane >= d) incl += up;
-                }
-                const uint32_t total = __shfl(incl, 63);
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                const uint32_t total = wave_read_lane(incl, 63);
                 if (x < before + total) {
                     const uint64_t m = __ballot(before + incl > x);
                     const uint32_t first = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-                    const uint32_t excl = __shfl(incl - cnt, first);
+                    const uint32_t excl = wave_read_lane(incl - cnt, first);
                     const uint32_t lighter = by_class && cls == 1u ? a.chunk_count[c0 + first] : 0u;      // the chunk's heavy records lie in front
                     found = (c0 + first) * LAS_PREPASS_BATCHES + lighter + (x - before - excl);
                     break;
