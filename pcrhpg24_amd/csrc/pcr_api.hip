@@ -396,6 +396,7 @@ uint32_t frame_dyn_lds(const pcr_ctx *c, int64_t nB)
     const uint32_t small = halves ? (uint32_t)DYN_LDS_BYTES_HALF : (uint32_t)DYN_LDS_BYTES, big = halves ? (uint32_t)DYN_LDS_BYTES_HALF_BIG : (uint32_t)DYN_LDS_BYTES_BIG;
     if (force && force[0] == 's') return small;
     if (force && force[0] == 'b') return big;
+    if (force && force[0] >= '1' && force[0] <= '9') return (uint32_t)atoi(force) * 1024u;     // KiB (must not exceed `big`)
     return (int64_t)c->width * c->height > nB * (int64_t)WIN_PIXELS ? big : small;
 }
 
@@ -527,7 +528,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r04.v104"; }
+const char *pcr_kernel_version(void) { return "r04.v106"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {

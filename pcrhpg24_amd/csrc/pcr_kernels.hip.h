@@ -309,39 +309,80 @@ __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_r
 // rectangle; the LOD arithmetic is uniform. One lane doing all of it serially made this launch 9 us of every frame.
 constexpr int PREPASS_LANES = 8;
 constexpr int PREPASS_BATCHES = PREPASS_THREADS / PREPASS_LANES;     // batches per workgroup
-__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
-__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int part, int j);
+struct PlanIn;
+__device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
+__device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int part, int j, const PlanIn &in);
+
+// What plan_windows reads from memory, requested at the top of the prepass block together with everything else the block
+// reads: the block sits on the critical path of every frame (it shares a launch with the resolve + clear of the frame before:
+// 7 us of work at 1080p) and was a chain of five dependent round trips (batch header -> the lod word read back -> list record ->
+// runs of chains -> the window plan read back): 12-14 us. Now: one round of loads, values handed on through LDS and registers.
+struct PlanIn {
+    uint32_t esc_count;             // escape words of the (batch, part)'s chains
+    uint32_t cut;                   // first chain of run r + 1 (runs[r]; unused for the last run)
+    float box[6], all[6];           // the run's box, the box of all the part's chains (k_bounds)
+    float gmin[3], gmax[3];         // the batch's own bounding box, relative to las_min (GPUBatch)
+};
+__device__ __forceinline__ PlanIn plan_preload(const RenderArgs &a, int64_t b, int part, int r)
+{
+    PlanIn in;
+    const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
+    const uint32_t mid = (uint32_t)ssz[511], total = (uint32_t)ssz[1023];
+    in.esc_count = a.parts == 1 ? total : part == 0 ? mid : total - mid;
+    const uint32_t *runs = a.s.batch_runs + ((size_t)b * RUN_RECORDS + run_record(a.parts, part)) * RUN_WORDS;
+    in.cut = runs[min(r, RUNS - 2)];
+    const float *box = reinterpret_cast<const float *>(runs + 4 + r * 6), *ab = reinterpret_cast<const float *>(runs + 4 + RUNS * 6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { in.box[k] = box[k]; in.all[k] = ab[k]; }
+    const pcr_gpu_batch *g = a.s.batches + b;
+    const float lm[3] = { (float)g->las_min_x, (float)g->las_min_y, (float)g->las_min_z };
+    in.gmin[0] = g->min_x - lm[0]; in.gmin[1] = g->min_y - lm[1]; in.gmin[2] = g->min_z - lm[2];
+    in.gmax[0] = g->max_x - lm[0]; in.gmax[1] = g->max_y - lm[1]; in.gmax[2] = g->max_z - lm[2];
+    return in;
+}
 
 __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t block)
 {
     const int64_t b = ((int64_t)block * PREPASS_THREADS + threadIdx.x) / PREPASS_LANES;
     const int lane = (int)(threadIdx.x % PREPASS_LANES);
     pcr_render_stats st = {0, 0, 0, 0};
-    // what k_render has to do for the group's batch: 0 nothing (culled, or no point to draw), 1 draw, 2 draw with the checked variant
-    __shared__ uint32_t s_kind[PREPASS_BATCHES];
-    if (lane == 0) s_kind[threadIdx.x / PREPASS_LANES] = 0;
-    if (b < a.s.num_batches) {
-        lod_prepass_batch(a, b, lane, st);                                                       // uniform per 8-lane group
-        if (lane == 0) {
-            const uint32_t lod = a.lod[b];
-            if (!(lod & LOD_CULLED) && (lod & LOD_NPR_MASK))
-                s_kind[threadIdx.x / PREPASS_LANES] = (a.s.batch_flags[b] & bf_generic(a.parts)) ? 2u : 1u;
-        }
+    // the group's lod word (LOD_*), handed to the compaction and to the window plan through LDS (0: no such batch)
+    __shared__ uint32_t s_lod[PREPASS_BATCHES];
+    // ---- every load of the block that does not depend on a result of the block, requested before anything is computed ----
+    // the record lanes (first wave, one per batch of the block): what a list record holds besides the lod word
+    const uint32_t bb = block * PREPASS_BATCHES + threadIdx.x;
+    uint32_t rec_flags = 0, rec_esc_total = 0, rec_esc_mid = 0;
+    int64_t rec_sep_off = 0;
+    if (threadIdx.x < PREPASS_BATCHES && (int64_t)bb < a.s.num_batches) {
+        rec_flags = a.s.batch_flags[bb];
+        rec_esc_total = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 1023];
+        rec_esc_mid = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 511];
+        rec_sep_off = a.s.batches[bb].separate_batch_offset;
     }
-    commit_stats(st, a.stats);                              // (barriers inside: s_kind is complete afterwards)
+    // the plan lanes: RUNS lanes per batch and part, one per run of chains
+    static_assert(PREPASS_BATCHES * RUNS * MAX_PARTS <= PREPASS_THREADS, "one round");
+    const uint32_t parts = (uint32_t)a.parts, plan_lanes = RUNS * parts;
+    const uint32_t slot = threadIdx.x / plan_lanes, part = (threadIdx.x / RUNS) % parts;
+    const int64_t pb = (int64_t)block * PREPASS_BATCHES + slot;
+    const bool plan_lane = threadIdx.x < PREPASS_BATCHES * plan_lanes && pb < a.s.num_batches;
+    PlanIn pin = {};
+    if (plan_lane) pin = plan_preload(a, pb, (int)part, (int)(threadIdx.x % RUNS));
+
+    if (lane == 0) s_lod[threadIdx.x / PREPASS_LANES] = LOD_CULLED;
+    if (b < a.s.num_batches) {
+        const uint32_t lod = lod_prepass_batch(a, b, lane, st);                                 // uniform per 8-lane group
+        if (lane == 0) s_lod[threadIdx.x / PREPASS_LANES] = lod;
+    }
+    commit_stats(st, a.stats);                              // (barriers inside: s_lod is complete afterwards)
     // first level of the compaction: one ballot and one prefix count per list, in the workgroup's first wave
     if (threadIdx.x < 64) {
-        const uint32_t kind = threadIdx.x < PREPASS_BATCHES ? s_kind[threadIdx.x] : 0u;
+        const uint32_t lod = threadIdx.x < PREPASS_BATCHES ? s_lod[threadIdx.x] : LOD_CULLED;
+        // what k_render has to do for the batch: 0 nothing (culled, or no point to draw), 1 draw, 2 draw with the checked variant
+        const uint32_t kind = !(lod & LOD_CULLED) && (lod & LOD_NPR_MASK) ? ((rec_flags & bf_generic(a.parts)) ? 2u : 1u) : 0u;
         const uint64_t below = (1ull << threadIdx.x) - 1ull;
         // (the list entry is the whole record k_render's workgroup starts from, see RenderArgs::order)
         DrawRec r = {0, 0, 0, 0, 0, 0};
-        if (kind) {
-            const uint32_t bb = block * PREPASS_BATCHES + threadIdx.x;
-            r.b = bb; r.lod = a.lod[bb];
-            r.esc_total = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 1023];
-            r.esc_mid = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 511];
-            r.sep_off = a.s.batches[bb].separate_batch_offset;
-        }
+        if (kind) { r.b = bb; r.lod = lod; r.esc_total = rec_esc_total; r.esc_mid = rec_esc_mid; r.sep_off = rec_sep_off; }
         // the ordinary list: class after class inside the chunk
         const uint32_t npr = r.lod & LOD_NPR_MASK;
         const uint32_t cls = a.work_classes > 1 && npr ? (uint32_t)(WORK_CLASSES - 1) - min((npr - 1u) / (64u / WORK_CLASSES), (uint32_t)(WORK_CLASSES - 1)) : 0u;
@@ -359,30 +400,31 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
             if (kind == 2u) a.order[(size_t)a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
         }
     }
-    // LDS framebuffer windows of the workgroups that draw: RUNS lanes per batch and part, one per run of chains
-    static_assert(PREPASS_BATCHES * RUNS * MAX_PARTS <= PREPASS_THREADS, "one round");
+    // LDS framebuffer windows of the workgroups that draw
     // ... and a vote: do (nearly) all of the workgroup's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
     // k_render pre-read the framebuffer words of such a batch's points (WinPlan::mostly_outside, project_request): a few batches of
     // that kind in a frame are cheaper unfiltered, a frame full of them (an unsorted stream) is not.
     __shared__ uint32_t s_vote[2];                          // plans drawn, of those mostly outside
     if (threadIdx.x < 2) s_vote[threadIdx.x] = 0;
     __syncthreads();
-    bool mine_drawn = false;
-    const uint32_t parts = (uint32_t)a.parts, plan_lanes = RUNS * parts;
-    const uint32_t slot = threadIdx.x / plan_lanes, part = (threadIdx.x / RUNS) % parts;
-    const int64_t pb = (int64_t)block * PREPASS_BATCHES + slot;
-    if (threadIdx.x < PREPASS_BATCHES * plan_lanes) {
-        if (pb < a.s.num_batches && s_kind[slot]) {
-            plan_windows(a, pb, (int)part, (int)(threadIdx.x % RUNS));                                   // (uniform per RUNS lanes)
+    bool mine_drawn = false, mine_outside = false;
+    if (plan_lane) {
+        const uint32_t lod = s_lod[slot];
+        if (!(lod & LOD_CULLED) && (lod & LOD_NPR_MASK)) {
+            const bool outside = plan_windows(a, pb, (int)part, (int)(threadIdx.x % RUNS), pin);     // (uniform per RUNS lanes)
             if (threadIdx.x % RUNS == 0) {
-                mine_drawn = true;
+                mine_drawn = true; mine_outside = outside;
                 atomicAdd(&s_vote[0], 1u);
-                if (a.win[pb * parts + part].mostly_outside) atomicAdd(&s_vote[1], 1u);     // (written by this lane a moment ago)
+                if (outside) atomicAdd(&s_vote[1], 1u);
             }
         }
     }
     __syncthreads();
-    if (mine_drawn && s_vote[1] * PCR_VOTE_DEN < s_vote[0] * PCR_VOTE_NUM) a.win[pb * parts + part].mostly_outside = 0;
+    // (the plan was written with the batch's own verdict; the neighbourhood's vote takes it back)
+    if (mine_drawn && mine_outside && s_vote[1] * PCR_VOTE_DEN < s_vote[0] * PCR_VOTE_NUM) {
+        a.win[pb * parts + part].mostly_outside = 0;
+        if (a.win_hqs) a.win_hqs[pb * parts + part].mostly_outside = 0;
+    }
 }
 
 // One lane per run: the screen rectangle of the run's bounding box (k_bounds), then LDS pixels for the RUNS rectangles. Only a
@@ -408,7 +450,8 @@ __device__ __forceinline__ void rect_pack(IRect r, uint32_t &xy, uint32_t &wh)
 
 // Windows for one pixel size, given the run's rectangle `mine` and the rectangle `single` that holds every chain of the workgroup
 // (uniform work per RUNS lanes).
-__device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect single, const uint32_t *runs, int r, WinPlan *out)
+// Returns the plan's own verdict "most points will land outside" (the same in every lane of the group).
+__device__ __forceinline__ bool assign_windows(int cap, IRect mine, IRect single, uint32_t cut, int r, WinPlan *out)
 {
     auto group_sum = [](int v) { v += __shfl_xor(v, 1, RUNS); v += __shfl_xor(v, 2, RUNS); return v; };
     auto group_max = [](int v) { v = max(v, __shfl_xor(v, 1, RUNS)); v = max(v, __shfl_xor(v, 2, RUNS)); return v; };
@@ -421,7 +464,7 @@ __device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect single
         out->xy[r] = xy; out->wh[r] = wh;                                           // (runs 1..3: no window of their own)
         if (r < RUNS - 1) out->first[r] = PCR_WORKGROUP_SIZE;                       // every chain belongs to run 0
         if (r == 0) out->mostly_outside = 0;
-        return;
+        return false;
     }
     // one window per run; while they do not fit together, the largest gives way (a run with a jump of its own inside)
     int sum = group_sum(rect_area(mine));
@@ -438,9 +481,11 @@ __device__ __forceinline__ void assign_windows(int cap, IRect mine, IRect single
     }
     if (sum > cap) mine = none;                                                     // hopeless: this run goes the global way
     rect_pack(mine, out->xy[r], out->wh[r]);
-    if (r < RUNS - 1) out->first[r] = min(runs[r], (uint32_t)PCR_WORKGROUP_SIZE);
+    if (r < RUNS - 1) out->first[r] = min(cut, (uint32_t)PCR_WORKGROUP_SIZE);
     const int kept = group_sum(rect_area(mine));                                    // (every lane of the group: a shuffle)
-    if (r == 0) out->mostly_outside = kept * 2 < wanted ? 1u : 0u;
+    const bool outside = kept * 2 < wanted;
+    if (r == 0) out->mostly_outside = outside ? 1u : 0u;
+    return outside;
 }
 
 // The screen rectangle of a box, worked out by a group of RUNS lanes (corners 2 r and 2 r + 1 per lane, then the union over the
@@ -483,16 +528,11 @@ __device__ __forceinline__ IRect rect_intersect(IRect a, IRect b)
     return c.x1 >= c.x0 && c.y1 >= c.y0 ? c : none;
 }
 
-__device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int part, int r)
+__device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int part, int r, const PlanIn &in)
 {
     const pcr_render_params &p = a.p;
     const float fw = (float)p.width, fh = (float)p.height;
-    const int32_t *ssz = a.s.separate_sizes + (size_t)b * 1024;
-    // the escape words of the workgroup's own chains (its pool, and what is left of the LDS for its windows)
-    const uint32_t esc_count = a.parts == 1 ? (uint32_t)ssz[1023] : part == 0 ? (uint32_t)ssz[511] : (uint32_t)(ssz[1023] - ssz[511]);
-    const uint32_t *runs = a.s.batch_runs + ((size_t)b * RUN_RECORDS + run_record(a.parts, part)) * RUN_WORDS;
-    const float *box = reinterpret_cast<const float *>(runs + 4 + r * 6);
-    const float bmin[3] = { box[0], box[1], box[2] }, bmax[3] = { box[3], box[4], box[5] };
+    const float bmin[3] = { in.box[0], in.box[1], in.box[2] }, bmax[3] = { in.box[3], in.box[4], in.box[5] };
     const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };      // identity of the union
     IRect mine = none;
     {
@@ -515,21 +555,10 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
         }
     }
     // the batch's own bounding box (GPUBatch: it holds every point but the garbage tails of SURVEY B.4): the dirty tiles are marked under it
-    IRect whole;
-    {
-        const pcr_gpu_batch *g = a.s.batches + b;
-        const float lm[3] = { (float)g->las_min_x, (float)g->las_min_y, (float)g->las_min_z };
-        const float gmin[3] = { g->min_x - lm[0], g->min_y - lm[1], g->min_z - lm[2] }, gmax[3] = { g->max_x - lm[0], g->max_y - lm[1], g->max_z - lm[2] };
-        whole = group_box_rect(p, gmin, gmax, r);
-    }
+    const IRect whole = group_box_rect(p, in.gmin, in.gmax, r);
     // ... and what k_bounds saw of the workgroup's own chains, garbage tails included (a hint: float dequantisation): the one
     // window of the workgroup if the LDS holds it
-    IRect single;
-    {
-        const float *ab = reinterpret_cast<const float *>(runs + 4 + RUNS * 6);
-        const float amin[3] = { ab[0], ab[1], ab[2] }, amax[3] = { ab[3], ab[4], ab[5] };
-        single = group_box_rect(p, amin, amax, r);
-    }
+    IRect single = group_box_rect(p, in.all, in.all + 3, r);
     if (rect_area(whole) > 0) {
         // No window reaches outside the rectangle the dirty tiles are marked under (FrameView::tiles): a point INSIDE its window is
         // never tested against that rectangle, so a window sticking out of it -- a run's box holds its chains' garbage tails -- would
@@ -538,9 +567,9 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
         single = rect_area(single) > 0 ? rect_intersect(single, whole) : whole;
         mine = rect_intersect(mine, whole);
     }
-    assign_windows(window_capacity(esc_count, a.win_pixel_bytes, a.dyn_lds_bytes, a.parts), mine, single, runs, r, a.win + b * a.parts + part);
+    const bool outside = assign_windows(window_capacity(in.esc_count, a.win_pixel_bytes, a.dyn_lds_bytes, a.parts), mine, single, in.cut, r, a.win + b * a.parts + part);
     if (a.win_hqs)                                              // (uniform) the colour pass of the same frame: 20-byte pixels
-        assign_windows(window_capacity(esc_count, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes, a.parts), mine, single, runs, r, a.win_hqs + b * a.parts + part);
+        assign_windows(window_capacity(in.esc_count, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes, a.parts), mine, single, in.cut, r, a.win_hqs + b * a.parts + part);
     // dirty tiles (FrameView::tiles): everything under the batch's rectangle; a batch without one can write anywhere
     uint32_t wxy = 0, wwh = 0;
     if (a.f.tiles) {
@@ -568,11 +597,12 @@ __device__ __forceinline__ void plan_windows(const RenderArgs &a, int64_t b, int
         w->whole_xy = wxy; w->whole_wh = wwh;
         if (a.win_hqs) { w = a.win_hqs + b * a.parts + part; w->whole_xy = wxy; w->whole_wh = wwh; }
     }
+    return outside;
 }
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
 
-__device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st)
+__device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st)
 {
     const uint32_t group_shift = (threadIdx.x & 63u) & ~(uint32_t)(PREPASS_LANES - 1);   // my group's bits in a wave ballot
     const pcr_gpu_batch g = a.s.batches[b];
@@ -596,7 +626,7 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
         if (votes != 0xFFu) {
             if (lane == 0) { a.lod[b] = LOD_CULLED; st.batches_culled = 1; }      // (plain stores to distinct fields: with `+=` hipcc
                                                                                       // merged them into one store at a computed offset -- scratch)
-            return;
+            return LOD_CULLED;
         }
     }
     // :349-375
@@ -623,12 +653,13 @@ __device__ __forceinline__ void lod_prepass_batch(const RenderArgs &a, int64_t b
     int npr = (int)(pct * (float)p.points_per_thread);                       // :375
     npr = min(npr, p.points_per_thread);
     npr = max(npr, 0);
+    const uint32_t lod = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
     if (lane == 0) {
-        a.lod[b] = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
+        a.lod[b] = lod;
         st.points_iterated = (int64_t)npr * PCR_WORKGROUP_SIZE;
         st.batches_double = use_double ? 1 : 0;
     }
-
+    return lod;
 }
 
 // ------------------------------------------------------------------------------------------------

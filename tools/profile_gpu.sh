@@ -1,13 +1,19 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the default bench workload.
 # Usage: tools/profile_gpu.sh <tag> [bench args...]     outputs under gpurun_out/prof_<tag>/
+#        PROFILE_SCRIPT=tools/bench_las.py PROFILE_KERNEL=k_las_render tools/profile_gpu.sh <tag> [args of that script]   (another workload)
 set -o pipefail
 TAG=${1:-r01}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="$PWD/bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline --no-variants --no-secondary $*"
-BENCH_FULL="$PWD/bench.py --no-cpu-baseline --no-variants --no-secondary $*"
+if [ -n "$PROFILE_SCRIPT" ]; then
+  BENCH="$PWD/$PROFILE_SCRIPT --steps 5 --warmup 2 --no-parity $*"
+  BENCH_FULL="$PWD/$PROFILE_SCRIPT --steps 200 --warmup 5 --no-parity $*"
+else
+  BENCH="$PWD/bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline --no-variants --no-secondary $*"
+  BENCH_FULL="$PWD/bench.py --no-cpu-baseline --no-variants --no-secondary $*"
+fi
 cd /tmp
 # the stats pass runs the bench at its default length so that its k_render average can be set beside roofline.kernel_ms
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $BENCH_FULL > "$OUT/stats.log" 2>&1 || { tail -20 "$OUT/stats.log"; exit 1; }

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--streams", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--variant", choices=["auto", "words", "point_windows"], default="auto", help="decode variant (pcr_set_render_variant)")
+    ap.add_argument("--parts", type=int, default=0, help="workgroups per batch (pcr_set_workgroup_parts): 0 = the library's choice, 1, 2")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     W, H = 480, 270
@@ -63,6 +64,7 @@ def main():
     if args.variant == "words":
         ctx.set_stream_layout(P.Context.LAYOUT_BOTH)          # both resident, the packed-words kernel forced
     ctx.set_render_variant({"auto": 0, "words": 1, "point_windows": 2}[args.variant])
+    ctx.set_workgroup_parts(args.parts)
     ctx.set_image_size(W, H)
     bad = enc_bad = 0
     t0 = time.time()

@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+KERNEL = os.environ.get("PROFILE_KERNEL", "k_render")      # dispatches whose PMC values are averaged
 
 
 def find(pattern):
@@ -20,13 +21,13 @@ for f in find("stats/**/*kernel_stats.csv"):
         print("%-70s calls %6s  total_ns %14s  avg_ns %12s  pct %6s" % (
             r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 
-print("\n== PMC (per-dispatch average over the k_render dispatches) ==")
+print("\n== PMC (per-dispatch average over the %s dispatches) ==" % KERNEL)
 for d in find("pmc*/"):
     for f in find(os.path.relpath(d, out) + "/**/*counter_collection.csv"):
         acc = defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
-            if "k_render" not in name:
+            if KERNEL not in name:
                 continue
             key = (name.split("(")[0][:60], r.get("Counter_Name"))
             acc[key][0] += float(r.get("Counter_Value", 0) or 0)
