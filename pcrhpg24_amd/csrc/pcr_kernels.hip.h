@@ -1807,7 +1807,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
                 ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);                 // :283-284
                 iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
                 // (inside <=> candidate here as well: for w > 0 the correctly rounded quotient lies in [-1,1] exactly when |x| <= w,
-                // a NaN or w <= 0 fails both forms, and a pixel of a point inside is below fb_elems -- Appendix C.2)
+                // a NaN or w < 0 fails both forms, and a pixel of a point inside is below fb_elems -- Appendix C.2. w == 0 with
+                // x == y == 0 -- a point exactly in the eye, or a degenerate matrix -- passes |x| <= w and is no candidate: :296 `w <= 0`)
+                cand_mask &= __builtin_amdgcn_ballot_w64(qw > 0.0f);
             }
             inside = __builtin_amdgcn_inverse_ballot_w64(cand_mask);
         };
@@ -2210,7 +2212,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
         const float qx = __fmaf_rn(m03, 1.0f, __fmaf_rn(m02, z, __fmaf_rn(m01, y, m00 * x)));
         const float qy = __fmaf_rn(m13, 1.0f, __fmaf_rn(m12, z, __fmaf_rn(m11, y, m10 * x)));
         const float qw = __fmaf_rn(m33, 1.0f, __fmaf_rn(m32, z, __fmaf_rn(m31, y, m30 * x)));
-        const uint64_t cand_mask = __builtin_amdgcn_ballot_w64(fabsf(qx) <= qw) & __builtin_amdgcn_ballot_w64(fabsf(qy) <= qw);
+        uint64_t cand_mask = __builtin_amdgcn_ballot_w64(fabsf(qx) <= qw) & __builtin_amdgcn_ballot_w64(fabsf(qy) <= qw);
         int ix, iy;
         {
             const float r0 = __builtin_amdgcn_rcpf(qw);
@@ -2228,6 +2230,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE, 8) k_las_render(LasArgs a)
             const float nx = qx / qw, ny = qy / qw;
             ix = (int)(__fmaf_rn(nx, 0.5f, 0.5f) * fw);
             iy = (int)(__fmaf_rn(ny, 0.5f, 0.5f) * fh);
+            cand_mask &= __builtin_amdgcn_ballot_w64(qw > 0.0f);            // (w == 0 with x == y == 0 passes |x| <= w: rasterize rejects w <= 0, :113)
         }
         scatter_pending();                                                   // the point before this one: its window word has arrived by now
         const uint32_t rx = (uint32_t)ix - wx0, ry = (uint32_t)iy - wy0;

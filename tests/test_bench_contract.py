@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORD = os.path.join(ROOT, "profiles", "r03_bench_basic.json")
+RECORD = os.path.join(ROOT, "profiles", "r04_bench_basic.json")
 
 
 @pytest.fixture(scope="module")
@@ -56,6 +56,9 @@ def test_measured_ceiling_and_traffic_are_reported(line):
     assert r["kernel_launches_timed"] >= 32
     one = line["cpu_baseline"]["single_core"]
     assert 0 < one["value"] < line["cpu_baseline"]["value"]
+    # single core AND all host cores; the 16-thread row stays the headline baseline
+    allc = line["cpu_baseline"]["all_cores"]
+    assert allc["cores"] == line["cpu_baseline"]["host_cores"] > line["cpu_baseline"]["cores"] and allc["value"] > one["value"]
 
 
 def test_both_variants_and_the_step_distribution_are_reported(line):
@@ -77,9 +80,27 @@ def test_both_variants_and_the_step_distribution_are_reported(line):
 
 def test_short_and_long_runs_agree():
     """with the clock pre-roll a 20-step run reports what the 200-step run reports (within 3 %)."""
-    with open(os.path.join(ROOT, "profiles", "r03_bench_basic20.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_basic20.json")) as f:
         short = json.loads(f.read().strip().splitlines()[-1])
     with open(RECORD) as f:
         long_ = json.loads(f.read().strip().splitlines()[-1])
     assert short["steps"] == 20 and long_["steps"] == 200
     assert abs(short["ms_per_step"] - long_["ms_per_step"]) / long_["ms_per_step"] < 0.03
+
+
+def test_secondary_rows(line):
+    """The rows SURVEY 8d / 8f and BASELINE configs[2], [4] ask for, on the same resident stream."""
+    sec = line["secondary"]
+    assert set(sec) >= {"lod10_cull1", "hqs", "4096_cull1", "4096_cull1_half", "las", "encoder"}
+    for name in ("lod10_cull1", "hqs", "4096_cull1", "4096_cull1_half"):
+        r = sec[name]
+        assert r["kernel_ms"] * r["kernel_launches_per_step"] <= r["ms_per_step"] and 0 < r["frac"] < 1, name
+    # the culling camera really culls: about half of the batches, so the prepass's compaction is on the timed path
+    half = sec["4096_cull1_half"]
+    assert 0.3 * line["config"]["batches_per_gpu"] < half["batches_culled"] < 0.7 * line["config"]["batches_per_gpu"]
+    assert sec["4096_cull1"]["batches_culled"] == 0
+    las = sec["las"]
+    assert las["parity_full_size"] is True and las["kernel"] == "k_las_render" and las["kernel_ms"] <= las["ms_per_step"]
+    assert abs(las["frac"] - las["algorithmic_bytes"] / (las["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+    enc = sec["encoder"]
+    assert enc["identical_to_cpu_encoder"] is True and enc["Mpoints_per_s"] > enc["cpu_encoder"]["Mpoints_per_s"]

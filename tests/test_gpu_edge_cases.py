@@ -293,3 +293,26 @@ def test_first_frame_releases_what_only_the_transcode_reads():
             c.close()
     # bytes per point resident: windows 5 + side data; packed words ~2.9 (per 64 chains the rows their longest chain consumed) + side data
     assert sizes["point_windows"] < 6.6 and sizes["words"] < 4.4 and sizes["point_windows"] + 2.5 < sizes["both"] < sizes["point_windows"] + 3.3
+
+
+def test_degenerate_matrices_w_zero_and_w_out_of_the_fast_range(ctx):
+    """rasterize() rejects `pos.w <= 0` (render.cu:296). The kernels' inside test is |x| <= w and |y| <= w -- true for x == y == w == 0,
+    a point exactly in the eye, or every point under an all-zero matrix -- so the slow division path (w outside [2^-64, 2^64)) has to
+    take such lanes out again. Also: matrices scaled by 2^-80 and 2^80 (every w outside the fast division's range: plain `/` for all
+    lanes) draw the frame of the unscaled matrix's pixels with the scaled depths."""
+    image, _ = scenes.synth_stream(200_000)
+    of = oracle.OracleFile(image.view())
+    ctx.set_image_size(320, 200)
+    load(ctx, image)
+    base = scenes.with_flags(scenes.cameras(320, 200)["overview"], lod_percent=100, cull=0)
+    zero = base.copy()
+    for k in range(16):
+        zero.transform[k] = 0.0
+    check_all(ctx, of, zero)
+    ctx.clear(); ctx.render_basic(zero)
+    assert (ctx.read_framebuffer(full=True) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()       # w == 0 everywhere: nothing is inside
+    for scale in (2.0 ** -80, 2.0 ** 80):
+        p = base.copy()
+        for k in range(16):
+            p.transform[k] = base.transform[k] * scale
+        check_all(ctx, of, p)

@@ -187,3 +187,21 @@ def test_las_several_chunks_of_the_draw_list():
                 assert st["batches_total"] == 301
     finally:
         r.ctx.close()
+
+
+def test_las_degenerate_matrices(renderer, cloud):
+    """rasterize() rejects w <= 0 (render.cu:113): under an all-zero matrix x == y == w == 0 passes the kernels' |x| <= w test and
+    has to be taken out again by the slow division path; matrices scaled by 2^-80 / 2^80 take that path for every point."""
+    pts, q = cloud
+    _load(renderer, pts)
+    base = scenes.with_flags(scenes.cameras(W, H)["overview"], cull=0)
+    zero = base.copy()
+    for k in range(16):
+        zero.transform[k] = 0.0
+    st = _check(renderer.ctx, q, zero)
+    assert (renderer.ctx.read_framebuffer(full=True) == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and st["points_iterated"] > 0
+    for scale in (2.0 ** -80, 2.0 ** 80):
+        p = base.copy()
+        for k in range(16):
+            p.transform[k] = base.transform[k] * scale
+        _check(renderer.ctx, q, p)
