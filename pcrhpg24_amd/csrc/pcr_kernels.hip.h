@@ -1325,16 +1325,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     // (requested two points earlier) and there is no queue.
     // LAYOUT_WORDS: my wave's rows of the batch's compact block (k_pack_words); a request past the last row the wave's longest
     // chain consumed is clamped to that row (such a word is requested ahead but never looked at)
-    const char *lwb = nullptr;
+    // (a pointer loaded from memory is a generic one to hipcc: flat_load_dword behind a 64-bit vector add per request. Said to be
+    // global, the block's base stays in a scalar register pair and a request is global_load_dword v, voffset, s[base:base+1])
+    typedef const __attribute__((address_space(1))) char *global_bytes;
+    global_bytes lwb = nullptr;
     uint32_t lw_last = 0;
     if (LAYOUT == LAYOUT_WORDS) {
         const uint32_t wave = __builtin_amdgcn_readfirstlane(chain >> 6);
         const uint32_t *wr = a.s.lw_wave_row + (size_t)b * (LWC_WAVES + 1) + wave;
         const uint32_t r0 = wr[0], r1 = wr[1];
-        lwb = reinterpret_cast<const char *>(a.s.lw_block[b]) + (size_t)r0 * LWC_ROW_BYTES;                      // uniform per wave
+        lwb = (global_bytes)(reinterpret_cast<const char *>(a.s.lw_block[b]) + (size_t)r0 * LWC_ROW_BYTES);      // uniform per wave
         lw_last = (r1 - r0 - 1u) * LWC_ROW_BYTES + (tid & 63u) * 4u;
     }
-    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(lwb + min(byte_off, lw_last)); };
+    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *(const __attribute__((address_space(1))) uint32_t *)(lwb + min(byte_off, lw_last)); };
     const char *pwb = reinterpret_cast<const char *>(a.s.point_windows) + (size_t)b * PW_BATCH_BYTES;               // uniform
     // the 40-bit window of a point as the top of a 64-bit view: high plane u32, low plane u8 (the 24 bits below are zero)
     // (per-lane byte offsets that advance by a row: with a uniform pointer that advances instead, hipcc adds the lane's
@@ -1482,10 +1485,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
         const uint32_t n2_ = k_ == 2u ? w2 : k_ == 1u ? far0 : far1;                       \
         w0 = n0_; w1 = n1_; w2 = n2_;                                                      \
         lwo += (2u - k_) * LWC_ROW_BYTES;                                                  \
-        /* only the words that moved up are fetched: 0.7 loads per point instead of 2 */   \
-        if (k_ == 1u) far0 = far1;                                                         \
-        if (k_ == 0u) far0 = lw_load(lwo);                                                 \
-        if (k_ != 2u) far1 = lw_load(lwo + LWC_ROW_BYTES);                                 \
+        /* the two words behind w2, requested afresh for every point (round 3 fetched only the words that moved up, 0.7 loads per \
+           point, under two branches: loads that may or may not have been issued make every later vmcnt wait a wait for all -- in the \
+           depth pass hipcc ended up waiting for this iteration's requests in the middle of the iteration) */ \
+        far0 = lw_load(lwo);                                                               \
+        far1 = lw_load(lwo + LWC_ROW_BYTES);                                               \
         bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare); \
         sft = SFT0;                                                                        \
     } while (0)
@@ -1511,7 +1515,11 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     // (tools/exp/instr_rate2.hip). The kernel has the registers to spare (<= 64 for eight waves per SIMD).
     // (only where there are registers to spare: not in the colour pass, which keeps its run of sums in registers, not with
     // the packed-words variant's five-word queue, not in the checked variant)
+#ifdef PCR_EXP_WORDS_VGPR_CONSTANTS
+    constexpr bool VGPR_CONSTANTS = !COLOR_PASS && !GENERIC;
+#else
     constexpr bool VGPR_CONSTANTS = !COLOR_PASS && LAYOUT == LAYOUT_POINT_WINDOWS && !GENERIC;
+#endif
     auto in_vgpr_f = [](float v) { if (!VGPR_CONSTANTS) return v; float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     auto in_vgpr_u = [](uint32_t v) { if (!VGPR_CONSTANTS) return v; uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; };
     const float m30 = in_vgpr_f(M[12]), m31 = in_vgpr_f(M[13]), m32 = in_vgpr_f(M[14]), m33 = in_vgpr_f(M[15]);   // the w row
