@@ -363,6 +363,7 @@ int enqueue_transcode(pcr_ctx *c, bool include_provisional, hipStream_t st)
                     total_rows += r;
                 }
                 uint32_t *seg = nullptr;
+                total_rows += LWC_PAD_ROWS;                 // (requests run up to four rows past a wave's last row: LWC_PAD_ROWS)
                 if (hipMalloc((void **)&seg, total_rows * LWC_ROW_BYTES) != hipSuccess)
                     return set_err(c, PCR_E_NOMEM, "out of device memory for %zu bytes of packed words", total_rows * (size_t)LWC_ROW_BYTES);
                 c->lw_segments.push_back(seg);
@@ -440,7 +441,7 @@ void maybe_finalize(pcr_ctx *c)
     if (*c->h_any_generic == 0) dfree_counted(c, c->d_table_values, nB * 4096);
     dfree_counted(c, c->d_lane_words, (size_t)std::min<int64_t>(TRANSCODE_CHUNK, (int64_t)nB) * LW_ROWS * PCR_WORKGROUP_SIZE);
     if (c->d_wave_rows) dfree_counted(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES);
-    if (c->d_lw_prov) dfree_counted(c, c->d_lw_prov, (size_t)LWC_WAVES * LW_ROWS * 64);
+    if (c->d_lw_prov) dfree_counted(c, c->d_lw_prov, (size_t)(LWC_WAVES * LW_ROWS + LWC_PAD_ROWS) * 64);
     c->finalized = true;
 }
 
@@ -528,7 +529,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r04.v107"; }
+const char *pcr_kernel_version(void) { return "r04.v108"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -656,7 +657,7 @@ int pcr_stream_begin(pcr_ctx *c, const pcr_file_header *h, int64_t batch_index_b
         (windows && (rc = dalloc_zero(c, c->d_point_windows, nB * PW_BATCH_BYTES + PW_GUARD_BYTES, acc))) ||
         (words && ((rc = dalloc_zero(c, c->d_lw_block, nB, acc)) || (rc = dalloc_zero(c, c->d_lw_wave_row, nB * (LWC_WAVES + 1), acc)) ||
                    (rc = dalloc_zero(c, c->d_wave_rows, (size_t)TRANSCODE_CHUNK * LWC_WAVES, acc)) ||
-                   (rc = dalloc_zero(c, c->d_lw_prov, (size_t)LWC_WAVES * LW_ROWS * 64, acc))))) {
+                   (rc = dalloc_zero(c, c->d_lw_prov, (size_t)(LWC_WAVES * LW_ROWS + LWC_PAD_ROWS) * 64, acc))))) {
         free_stream_buffers(c);
         return rc;
     }

@@ -89,6 +89,10 @@ constexpr uint32_t LW_ROW_BYTES = PCR_WORKGROUP_SIZE * 4;
 // bytes each, one block per batch. The benchmark stream's chains take 43.6 words on average, a wave's longest 46.7, against
 // the 80 rows of the transcode's scratch form: 2.9 B per point resident instead of 5.
 constexpr uint32_t LWC_ROW_BYTES = 64 * 4;
+// Rows allocated behind the last wave's rows of a segment: a chain requests the two words behind its view for every point, up to four rows
+// past the last row its wave's longest chain consumed (2 preloaded + every retired word + 1) -- words nobody looks at (a code's table
+// entry does not depend on the bits behind the code), read from the next wave's rows or from this pad instead of being clamped
+constexpr uint32_t LWC_PAD_ROWS = 8;
 constexpr int LWC_WAVES = PCR_WORKGROUP_SIZE / 64;          // 16 blocks of rows per batch + one entry for the end
 // Point windows (k_transcode, layout PCR_LAYOUT_POINT_WINDOWS): for point i of every chain the 40 bits of the chain's own
 // bit stream that start at the point's first bit -- its three symbols (<= 36 bits) lie inside. Stored as two planes per
@@ -1324,20 +1328,19 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     // LAYOUT_POINT_WINDOWS: the view of every point was cut by k_transcode; row i of point_windows is read at point i
     // (requested two points earlier) and there is no queue.
     // LAYOUT_WORDS: my wave's rows of the batch's compact block (k_pack_words); a request past the last row the wave's longest
-    // chain consumed is clamped to that row (such a word is requested ahead but never looked at)
+    // chain consumed reads the next wave's rows or the segment's pad (LWC_PAD_ROWS: such a word is requested ahead but never looked at)
     // (a pointer loaded from memory is a generic one to hipcc: flat_load_dword behind a 64-bit vector add per request. Said to be
     // global, the block's base stays in a scalar register pair and a request is global_load_dword v, voffset, s[base:base+1])
     typedef const __attribute__((address_space(1))) char *global_bytes;
     global_bytes lwb = nullptr;
-    uint32_t lw_last = 0;
     if (LAYOUT == LAYOUT_WORDS) {
         const uint32_t wave = __builtin_amdgcn_readfirstlane(chain >> 6);
         const uint32_t *wr = a.s.lw_wave_row + (size_t)b * (LWC_WAVES + 1) + wave;
         const uint32_t r0 = wr[0], r1 = wr[1];
         lwb = (global_bytes)(reinterpret_cast<const char *>(a.s.lw_block[b]) + (size_t)r0 * LWC_ROW_BYTES);      // uniform per wave
-        lw_last = (r1 - r0 - 1u) * LWC_ROW_BYTES + (tid & 63u) * 4u;
+        (void)r1;
     }
-    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *(const __attribute__((address_space(1))) uint32_t *)(lwb + min(byte_off, lw_last)); };
+    auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *(const __attribute__((address_space(1))) uint32_t *)(lwb + byte_off); };
     const char *pwb = reinterpret_cast<const char *>(a.s.point_windows) + (size_t)b * PW_BATCH_BYTES;               // uniform
     // the 40-bit window of a point as the top of a 64-bit view: high plane u32, low plane u8 (the 24 bits below are zero)
     // (per-lane byte offsets that advance by a row: with a uniform pointer that advances instead, hipcc adds the lane's
