@@ -10,10 +10,10 @@
 //                   (render.cu:404-451), recording per chain the words it receives -> lane-major stream, 40-bit point windows,
 //                   packed decoder table, colour blocks in segment-major order
 //   k_bounds        once per loaded batch: where the batch's chains fall apart into spatial clusters (runs of chains + boxes)
-//   k_render<MODE>  every frame, one 1024-thread workgroup per batch, one chain per lane: decodes the chain of
-//                   <= 64 points from its own bits with the batch's decoder table in LDS, then projects
-//                   and scatters every point (render.cu:383-540, huffman_hqs/depth.cu, huffman_hqs/render.cu; MODE 3: the
-//                   colour pass over BC7 mode-6 colours)
+//   k_render<MODE>  every frame, one chain per lane -- two 512-thread workgroups per batch (PARTS = 2, the default) or the reference's
+//                   one of 1024 (PARTS = 1): decodes the chain of <= 64 points from its own bits with the batch's decoder table in
+//                   LDS, then projects and scatters every point (render.cu:383-540, huffman_hqs/depth.cu, huffman_hqs/render.cu;
+//                   MODE 3: the colour pass over BC7 mode-6 colours)
 //   k_las_*         the 10-10-10 method (modules/compute_loop_las_cuda)
 //   k_resolve_*     framebuffer -> RGBA8 (resolve.cu:149-191, huffman_hqs/resolve.cu:2-47)
 //   k_merge_* / k_flip_sign  multi-GPU partial-framebuffer merges
@@ -32,7 +32,7 @@ constexpr uint32_t LOD_CULLED   = 0x200u;
 
 enum { MODE_BASIC = 0, MODE_HQS_DEPTH = 1, MODE_HQS_COLOR = 2, MODE_HQS_COLOR_BC7 = 3 };   // (3: the colour pass over BC7 mode-6 colours)
 
-// k_render's LDS plan (76 KiB per 1024-thread workgroup -> two workgroups per CU)
+// k_render's LDS plan (whole-batch workgroups: 76 KiB per 1024 threads -> two per CU; half-batch workgroups: see DYN_LDS_BYTES_HALF)
 constexpr int CHUNK_WORDS    = 64;               // stream staging granule per cluster: 32 lanes x 2 words (8-byte loads)
 constexpr int RING_WORDS     = 2 * CHUNK_WORDS;  // per cluster                                   -> 16 KiB
 // 60 KiB of k_render's LDS are shared between the batch's escape words and its framebuffer window, divided per batch: the
@@ -669,7 +669,7 @@ __device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64
 // ------------------------------------------------------------------------------------------------
 // decode + rasterize: one workgroup per batch, one chain per lane (lanes are independent after k_transcode)
 //
-// Memory plan per workgroup (LDS 76 KiB -> two workgroups per CU, 8 waves per SIMD):
+// Memory plan per workgroup (PARTS = 1: LDS 76 KiB -> two workgroups per CU; PARTS = 2: 40 KiB -> four; 8 waves per SIMD either way):
 //   s_table  16 KiB  decoder table packed to one dword per key (TE_* above): value << 10 | wide << 9 | escape << 8 | len
 //                    (an in-table value outside +-2^21 is flagged `wide` and re-read from global memory)
 //   s_dyn    60 KiB  (or 140 KiB) shared per batch (see DYN_LDS_BYTES above) between
