@@ -504,6 +504,15 @@ def main():
                 of.render_basic(p.copy(), first=0, count=sample, nthreads=allc)
                 sa += time.perf_counter() - t0
                 fr += 1
+            # (where between 16 threads and all of them does the host stop scaling? two frames per thread count)
+            sweep = {}
+            for nt in (32, 64, 128):
+                if nthreads < nt < allc:
+                    of.render_basic(p.copy(), first=0, count=sample, nthreads=nt)
+                    t0 = time.perf_counter()
+                    of.render_basic(p.copy(), first=0, count=sample, nthreads=nt)
+                    sweep[str(nt)] = round(osta["points_iterated"] / (time.perf_counter() - t0) / 1e6, 1)
+            cpu_baseline["thread_sweep"] = sweep
             cpu_baseline["all_cores"] = {"value": round(fr * osta["points_iterated"] / sa / 1e6, 3), "unit": "Mpoints/s", "cores": allc,
                                          "sample": "%d frame(s) of %d batches, one thread per host core, one shared framebuffer (compare-exchange min), %.2f s wall"
                                                    % (fr, sample, sa)}
