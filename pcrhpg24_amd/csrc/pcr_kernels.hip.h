@@ -1342,17 +1342,22 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     }
     auto lw_load = [&](uint32_t byte_off) -> uint32_t { return *(const __attribute__((address_space(1))) uint32_t *)(lwb + byte_off); };
     const char *pwb = reinterpret_cast<const char *>(a.s.point_windows) + (size_t)b * PW_BATCH_BYTES;               // uniform
-    // the 40-bit window of a point as the top of a 64-bit view: high plane u32, low plane u8 (the 24 bits below are zero)
-    // (per-lane byte offsets that advance by a row: with a uniform pointer that advances instead, hipcc adds the lane's
-    // offset to it with a 64-bit vector add in front of every load)
-    auto pw_load_hi = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pwb + byte_off); };
+    // the 40-bit window of a point as the top of a 64-bit view: high plane u32, low plane u8 (the 24 bits below are zero).
+    // Window rows come through buffer loads: the lane's column offset stays put in a vector register, the row advances in a scalar
+    // one (buffer_load_dword v, voffset, s[rsrc], soffset offen) -- no vector add per row and plane (with plain pointers hipcc either
+    // advanced a per-lane offset or added the lane's offset to an advancing uniform pointer with a 64-bit vector add). Reads past the
+    // batch's block + guard return 0. (HQS -0.7 %, LOD 10 % -1.2 %, LOD 100 % within the noise: the two adds were of the cheap class.)
+    const __amdgpu_buffer_rsrc_t pw_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)const_cast<char *>(pwb), 0, (int)(PW_BATCH_BYTES + PW_GUARD_BYTES), 0x00020000);
+    uint32_t pw_row_hi = 0, pw_row_lo = PW_HI_BYTES;        // (uniform) byte offsets of the current row in the two planes
+    const uint32_t pw_col_hi = chain * 4, pw_col_lo = chain;
+    auto pw_load_hi = [&]() -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pw_rsrc, (int)pw_col_hi, (int)pw_row_hi, 0); };
 #ifdef PCR_EXP_NO_LO      // timing experiment only (wrong frames): what 32-bit windows would save -- the low plane is never read
-    auto pw_load_lo = [&](uint32_t) -> uint32_t { return 0u; };
+    auto pw_load_lo = [&]() -> uint32_t { return 0u; };
 #else
-    auto pw_load_lo = [&](uint32_t byte_off) -> uint32_t { return *reinterpret_cast<const uint8_t *>(pwb + byte_off); };
+    auto pw_load_lo = [&]() -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(pw_rsrc, (int)pw_col_lo, (int)pw_row_lo, 0); };
 #endif
-    uint32_t lwo = LAYOUT == LAYOUT_WORDS ? (tid & 63u) * 4 : chain * 4;   // byte offset of my column in the row of far0 / in the high plane's row
-    uint32_t lwo2 = PW_HI_BYTES + chain;                    // ... in the low plane's row
+#define PCR_PW_NEXT_ROW() do { pw_row_hi += PW_HI_ROW_BYTES; pw_row_lo += PW_LO_ROW_BYTES; } while (0)
+    uint32_t lwo = (tid & 63u) * 4;                         // packed words: byte offset of my column in the row of far0
     uint32_t w0 = 0, w1 = 0, w2 = 0, far0 = 0, far1 = 0, spare = 0;
     uint64_t bits;
     uint32_t nwin_hi = 0, nwin_lo = 0;
@@ -1362,9 +1367,9 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
         lwo += 2 * LWC_ROW_BYTES;
         bits = ((uint64_t)__builtin_amdgcn_alignbit(w0, w1, spare) << 32) | __builtin_amdgcn_alignbit(w1, w2, spare);
     } else {
-        bits = ((uint64_t)pw_load_hi(lwo) << 32) | (pw_load_lo(lwo2) << 24);
-        lwo += PW_HI_ROW_BYTES; lwo2 += PW_LO_ROW_BYTES;
-        nwin_hi = pw_load_hi(lwo); nwin_lo = pw_load_lo(lwo2) << 24;
+        bits = ((uint64_t)pw_load_hi() << 32) | (pw_load_lo() << 24);
+        PCR_PW_NEXT_ROW();
+        nwin_hi = pw_load_hi(); nwin_lo = pw_load_lo() << 24;
     }
     constexpr uint32_t SFT0 = 50;                           // (bits >> 50) & 0x3FFC = 4 x the top 12 bits of the view
     uint32_t sft = SFT0;
@@ -1386,8 +1391,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
     // BC1 blocks of my chain (4 blocks of 16 points, 8 bytes each): the block of the current 16-point segment in
     // registers, the next one prefetched a whole segment (16 iterations) before its first use
     const uint2 *cblocks = reinterpret_cast<const uint2 *>(a.s.colors_t) + ((size_t)b * 4096 + chain);        // [segment][chain]
-    Bc1Palette pal = {0, 0, 0, 0};
     uint2 cnext = make_uint2(0, 0);
+    Bc1Palette pal = {0, 0, 0, 0};
     if (MODE != MODE_HQS_DEPTH && !BC7) cnext = cblocks[0];
     // (BC7 colours, 16 bytes per block: the block of a segment is read at its start -- no register for a prefetched one)
     const uint4 *blocks7 = reinterpret_cast<const uint4 *>(a.s.colors_t) + ((size_t)b * 4096 + chain);
@@ -1671,6 +1676,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
           if (BC7) pal7 = bc7_block(blocks7[(seg >> 4) * PCR_WORKGROUP_SIZE]);
           else {
               pal = bc1_palette(cnext);                 // once per 16 points instead of once per surviving point
+                                                        // (palettes expanded at load time, 16 bytes per block: measured twice, rounds 2 and 4: nothing)
               cnext = cblocks[min((seg >> 4) + 1, 3) * PCR_WORKGROUP_SIZE];
           }
       }
@@ -1681,8 +1687,8 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE / PARTS, 8) k_render(Render
         if (LAYOUT == LAYOUT_POINT_WINDOWS) {
             // row i+2, requested at the top of point i and taken over at its very end: a whole point of latency cover
             // (past row 63 of a plane lies the batch's other plane, the next batch, or the guard)
-            lwo += PW_HI_ROW_BYTES; lwo2 += PW_LO_ROW_BYTES;
-            fetched_hi = pw_load_hi(lwo); fetched_lo = pw_load_lo(lwo2);
+            PCR_PW_NEXT_ROW();
+            fetched_hi = pw_load_hi(); fetched_lo = pw_load_lo();
         }
 #if defined(PCR_EXP_PAD_FAST) || defined(PCR_EXP_PAD_SLOW) || defined(PCR_EXP_PAD_SALU)   /* experiment: what one more instruction per point costs */
         {

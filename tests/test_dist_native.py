@@ -132,6 +132,8 @@ def test_one_rank_communicator_frames_match_the_oracle():
         assert lib.pcr_dist_unique_id(ident) == 0, lib.pcr_dist_last_error()
         assert lib.pcr_dist_create(r.ctx.h, ident, 0, 1, C.byref(d)) == 0, lib.pcr_dist_last_error()
         assert lib.pcr_dist_world(d) == 1 and lib.pcr_dist_rank(d) == 0
+        lib.pcr_dist_comm_ranks.argtypes = [C.c_void_p]
+        assert lib.pcr_dist_comm_ranks(d) == 1                  # ncclCommCount: what bench.py quotes as rccl_ranks
         ofb, ost = of.render_basic(p)
         for root in (0, -1):                              # reduce to rank 0, all-reduce
             assert lib.pcr_dist_frame_basic(d, C.byref(p), root) == 0, lib.pcr_dist_last_error()
