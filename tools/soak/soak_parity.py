@@ -22,13 +22,14 @@ def main():
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--variant", choices=["auto", "words", "point_windows"], default="auto", help="decode variant (pcr_set_render_variant)")
+    ap.add_argument("--points", type=int, default=2_000_000, help="points of the synthetic stream (2e7: 306 batches, ten prepass workgroups)")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per batch (pcr_set_workgroup_parts): 0 = the library's choice, 1, 2")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
-    image, _ = scenes.synth_stream(2_000_000)
+    image, _ = scenes.synth_stream(args.points)
     of = oracle.OracleFile(image.view())
     hf = P.HuffmanFile(image)
-    n = 2_000_000
+    n = args.points
     x, y, z, c = P.synth_points(n, scenes.SEED, 0, n)
     las = P.synth_las_info(n, scenes.SEED)
     q = P.las_quantize(x, y, z, c, las)
