@@ -562,9 +562,13 @@ def main():
         variants[other] = variant_record(other, 1e3 * e2 / n2, k2, ctx.resident_bytes)
 
     # ---- the rows SURVEY 8f built next, on contexts of their own (N == 1 only): the 10-10-10 method and the GPU encoder -------------
+    # (a failure in one of these rows must not cost the line its headline: it is recorded in the row's place)
     if world == 1 and not use_dist and not args.no_secondary and rank == 0:
-        secondary["las"] = las_row(P, local_rank, args)
-        secondary["encoder"] = encoder_row(P, local_rank, args, nthreads)
+        for name, row in (("las", lambda: las_row(P, local_rank, args)), ("encoder", lambda: encoder_row(P, local_rank, args, nthreads))):
+            try:
+                secondary[name] = row()
+            except Exception as e:          # noqa: BLE001
+                secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if args.method == "hqs":
         merge_desc = "min all-reduce of the depth + sum %s of the colour sums" % (
