@@ -478,7 +478,7 @@ template <int MODE> int launch_render(pcr_ctx *c, const pcr_render_params *p)
         if (MODE == MODE_HQS_DEPTH) a.win_hqs = plan_slot[1];
         slots = MODE == MODE_HQS_DEPTH ? 3u : my_slot;
         c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
-        hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials), dim3(PREPASS_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL(k_lod_prepass, dim3((unsigned)c->stats_partials * PREPASS_WGS_PER_CHUNK), dim3(PREPASS_THREADS), 0, c->stream, a);
         a.win_hqs = nullptr;
     }
     if (MODE == MODE_HQS_DEPTH && (slots & 2u)) {
@@ -529,7 +529,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r04.v109"; }
+const char *pcr_kernel_version(void) { return "r04.v110"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
@@ -1072,8 +1072,9 @@ int pcr_frame_begin(pcr_ctx *c, const pcr_render_params *p, int method)
     if (method == PCR_METHOD_HQS) a.win_hqs = c->d_win + c->hdr.num_batches * MAX_PARTS;     // ... and the colour pass's plan with it
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
-    hipLaunchKernelGGL(k_frame_begin, dim3((unsigned)c->stats_partials + 2048u), dim3(256), 0, c->stream, a,
-                       (uint32_t)c->stats_partials, c->fb, rg, ba, c->fb_elems, c->empty_key, tflags);
+    const uint32_t prepass_wgs = (uint32_t)c->stats_partials * PREPASS_WGS_PER_CHUNK;       // (two workgroups per chunk: lists / plans)
+    hipLaunchKernelGGL(k_frame_begin, dim3(prepass_wgs + 2048u), dim3(256), 0, c->stream, a,
+                       prepass_wgs, c->fb, rg, ba, c->fb_elems, c->empty_key, tflags);
     HIP_TRY(c, hipGetLastError());
     c->accum_dirty = false;
     c->prepass_ready = true;
@@ -1115,6 +1116,7 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
     if (hqs) a.win_hqs = c->d_win + c->hdr.num_batches * MAX_PARTS;
     a.dyn_lds_bytes = frame_dyn_lds(c, nB);
     c->stats_partials = (int)((nB + PREPASS_BATCHES - 1) / PREPASS_BATCHES);
+    const uint32_t prepass_wgs = (uint32_t)c->stats_partials * PREPASS_WGS_PER_CHUNK;       // (two workgroups per chunk: lists / plans)
     const uint32_t pixels = (uint32_t)((size_t)c->width * c->height);
     if (c->tiles_usable() && c->tiles_tracked) {
         // only the tiles something was written in (and those the image still holds something in): FrameView::tiles
@@ -1126,21 +1128,21 @@ int pcr_frame_turn(pcr_ctx *c, const pcr_render_params *p_done, const pcr_render
         c->tile_cur = spare; c->tile_prev = cur; c->tile_spare = prev;
         c->tile_e_prev = c->tile_e_cur; c->tile_e_cur = ++c->tile_epochs;
         a.f.tiles = c->tiles_half(c->tile_cur); a.f.tiles_all = c->tiles_all(c->tile_cur); a.f.tiles_epoch = c->tile_e_cur;      // (the prepass of the next frame)
-        const unsigned grid = (unsigned)c->stats_partials + std::min<unsigned>(c->ntiles, 4096u);
-        if (hqs) hipLaunchKernelGGL(k_frame_turn_tiles<true>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+        const unsigned grid = prepass_wgs + std::min<unsigned>(c->ntiles, 4096u);
+        if (hqs) hipLaunchKernelGGL(k_frame_turn_tiles<true>, dim3(grid), dim3(256), 0, c->stream, a, prepass_wgs, p_done->show_num_points,
                                     p_done->colorize_chunks, (uint32_t)c->width, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key,
                                     tf, c->tiles_x);
-        else     hipLaunchKernelGGL(k_frame_turn_tiles<false>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+        else     hipLaunchKernelGGL(k_frame_turn_tiles<false>, dim3(grid), dim3(256), 0, c->stream, a, prepass_wgs, p_done->show_num_points,
                                     p_done->colorize_chunks, (uint32_t)c->width, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key,
                                     tf, c->tiles_x);
     } else {
-        const unsigned grid = (unsigned)c->stats_partials + 2048u;
+        const unsigned grid = prepass_wgs + 2048u;
         const TileFlags tflags = tiles_at_clear(c);
         a.f.tiles = c->tiles_tracked ? c->tiles_half(c->tile_cur) : nullptr;     // (the prepass of the next frame marks the fresh array)
         a.f.tiles_all = c->d_tiles ? c->tiles_all(c->tile_cur) : nullptr; a.f.tiles_epoch = c->tile_e_cur;
-        if (hqs) hipLaunchKernelGGL(k_frame_turn<true>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+        if (hqs) hipLaunchKernelGGL(k_frame_turn<true>, dim3(grid), dim3(256), 0, c->stream, a, prepass_wgs, p_done->show_num_points,
                                     p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key, tflags);
-        else     hipLaunchKernelGGL(k_frame_turn<false>, dim3(grid), dim3(256), 0, c->stream, a, (uint32_t)c->stats_partials, p_done->show_num_points,
+        else     hipLaunchKernelGGL(k_frame_turn<false>, dim3(grid), dim3(256), 0, c->stream, a, prepass_wgs, p_done->show_num_points,
                                     p_done->colorize_chunks, pixels, c->fb, c->rg, c->ba, c->d_rgba, (uint32_t)c->fb_elems, c->empty_key, tflags);
     }
     HIP_TRY(c, hipGetLastError());

@@ -241,6 +241,13 @@ struct RenderArgs {
     uint32_t dyn_lds_bytes;   // dynamic LDS of the following k_render launch: DYN_LDS_BYTES or DYN_LDS_BYTES_BIG
 };
 
+#ifdef PCR_EXP_TIMELINE   /* experiment: wall-clock stamps (100 MHz) of the prepass block's phases, rows 7000 + block of g_timeline */
+extern __device__ unsigned long long g_timeline[8192 * 8];
+#define PCR_PTL(slot) do { if (threadIdx.x == 0) g_timeline[(size_t)(7000 + block * 2 + (LISTS ? 0 : 1)) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PCR_PTL(slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // wave64 inclusive prefix sum in six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast 15 / 31 across
 // them): no LDS, no wait. (__shfl_up compiles to ds_bpermute_b32: the scans at the top of k_render -- one per class of the list,
@@ -288,7 +295,7 @@ constexpr int PREPASS_THREADS = 256;
 constexpr int PCR_MAX_PREPASS_WORKGROUPS = 2048;        // ceil(65535 batches / 32 batches per prepass workgroup)
 constexpr int WORK_CLASSES = 4;                         // of the ordinary list, by points per chain: 49..64, 33..48, 17..32, 1..16 (RenderArgs::work_classes;
                                                         // 2, 3 and 4 classes measure alike, 8 cost the light workgroups' scans more than they gain)
-__device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_render_stats *partials)
+__device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_render_stats *partials, uint32_t index)
 {
     __shared__ unsigned long long s_sum[4];
     if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
@@ -302,7 +309,7 @@ __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_r
         pcr_render_stats r;
         r.batches_total = (int64_t)s_sum[0]; r.batches_culled = (int64_t)s_sum[1];
         r.points_iterated = (int64_t)s_sum[2]; r.batches_double = (int64_t)s_sum[3];
-        partials[blockIdx.x] = r;
+        partials[index] = r;
     }
 }
 
@@ -314,7 +321,7 @@ __device__ __forceinline__ void commit_stats(const pcr_render_stats &mine, pcr_r
 constexpr int PREPASS_LANES = 8;
 constexpr int PREPASS_BATCHES = PREPASS_THREADS / PREPASS_LANES;     // batches per workgroup
 struct PlanIn;
-__device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st);
+__device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st, bool publish);
 __device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int part, int j, const PlanIn &in);
 
 // What plan_windows reads from memory, requested at the top of the prepass block together with everything else the block
@@ -345,19 +352,26 @@ __device__ __forceinline__ PlanIn plan_preload(const RenderArgs &a, int64_t b, i
     return in;
 }
 
-__device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t block)
+// The prepass of a chunk of PREPASS_BATCHES batches is done by TWO workgroups of the launch, side by side (round 4): one writes what
+// k_render's scan reads (lod words, statistics, the compacted lists), the other the window plans, the dirty tiles and the vote. Both
+// work out the chunk's cull / LOD decisions for themselves (a microsecond of arithmetic on CUs that have nothing else to do): the
+// block is a chain of cold starts -- kernel arguments, instruction cache, one round of loads -- and sits on every frame's critical
+// path; as one workgroup it took 8.6-10.1 us from its start (phase stamps: tools/exp/prepass_timeline.py), of which the plans 2.8-4.5.
+template <bool LISTS>
+__device__ __forceinline__ void lod_prepass_chunk(const RenderArgs &a, uint32_t block)
 {
     const int64_t b = ((int64_t)block * PREPASS_THREADS + threadIdx.x) / PREPASS_LANES;
     const int lane = (int)(threadIdx.x % PREPASS_LANES);
     pcr_render_stats st = {0, 0, 0, 0};
-    // the group's lod word (LOD_*), handed to the compaction and to the window plan through LDS (0: no such batch)
+    PCR_PTL(0);
+    // the group's lod word (LOD_*), handed to the compaction / to the window plan through LDS (LOD_CULLED: no such batch)
     __shared__ uint32_t s_lod[PREPASS_BATCHES];
     // ---- every load of the block that does not depend on a result of the block, requested before anything is computed ----
     // the record lanes (first wave, one per batch of the block): what a list record holds besides the lod word
     const uint32_t bb = block * PREPASS_BATCHES + threadIdx.x;
     uint32_t rec_flags = 0, rec_esc_total = 0, rec_esc_mid = 0;
     int64_t rec_sep_off = 0;
-    if (threadIdx.x < PREPASS_BATCHES && (int64_t)bb < a.s.num_batches) {
+    if (LISTS && threadIdx.x < PREPASS_BATCHES && (int64_t)bb < a.s.num_batches) {
         rec_flags = a.s.batch_flags[bb];
         rec_esc_total = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 1023];
         rec_esc_mid = (uint32_t)a.s.separate_sizes[(size_t)bb * 1024 + 511];
@@ -368,49 +382,57 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
     const uint32_t parts = (uint32_t)a.parts, plan_lanes = RUNS * parts;
     const uint32_t slot = threadIdx.x / plan_lanes, part = (threadIdx.x / RUNS) % parts;
     const int64_t pb = (int64_t)block * PREPASS_BATCHES + slot;
-    const bool plan_lane = threadIdx.x < PREPASS_BATCHES * plan_lanes && pb < a.s.num_batches;
+    const bool plan_lane = !LISTS && threadIdx.x < PREPASS_BATCHES * plan_lanes && pb < a.s.num_batches;
     PlanIn pin = {};
     if (plan_lane) pin = plan_preload(a, pb, (int)part, (int)(threadIdx.x % RUNS));
 
+    PCR_PTL(1);
     if (lane == 0) s_lod[threadIdx.x / PREPASS_LANES] = LOD_CULLED;
     if (b < a.s.num_batches) {
-        const uint32_t lod = lod_prepass_batch(a, b, lane, st);                                 // uniform per 8-lane group
+        const uint32_t lod = lod_prepass_batch(a, b, lane, st, LISTS);                          // uniform per 8-lane group
         if (lane == 0) s_lod[threadIdx.x / PREPASS_LANES] = lod;
     }
-    commit_stats(st, a.stats);                              // (barriers inside: s_lod is complete afterwards)
-    // first level of the compaction: one ballot and one prefix count per list, in the workgroup's first wave
-    if (threadIdx.x < 64) {
-        const uint32_t lod = threadIdx.x < PREPASS_BATCHES ? s_lod[threadIdx.x] : LOD_CULLED;
-        // what k_render has to do for the batch: 0 nothing (culled, or no point to draw), 1 draw, 2 draw with the checked variant
-        const uint32_t kind = !(lod & LOD_CULLED) && (lod & LOD_NPR_MASK) ? ((rec_flags & bf_generic(a.parts)) ? 2u : 1u) : 0u;
-        const uint64_t below = (1ull << threadIdx.x) - 1ull;
-        // (the list entry is the whole record k_render's workgroup starts from, see RenderArgs::order)
-        DrawRec r = {0, 0, 0, 0, 0, 0};
-        if (kind) { r.b = bb; r.lod = lod; r.esc_total = rec_esc_total; r.esc_mid = rec_esc_mid; r.sep_off = rec_sep_off; }
-        // the ordinary list: class after class inside the chunk
-        const uint32_t npr = r.lod & LOD_NPR_MASK;
-        const uint32_t cls = a.work_classes > 1 && npr ? (uint32_t)(WORK_CLASSES - 1) - min((npr - 1u) / (64u / WORK_CLASSES), (uint32_t)(WORK_CLASSES - 1)) : 0u;
-        uint32_t base = 0;
+    PCR_PTL(2);
+    if (LISTS) {
+        commit_stats(st, a.stats, block);                   // (barriers inside: s_lod is complete afterwards)
+        PCR_PTL(3);
+        // first level of the compaction: one ballot and one prefix count per list, in the workgroup's first wave
+        if (threadIdx.x < 64) {
+            const uint32_t lod = threadIdx.x < PREPASS_BATCHES ? s_lod[threadIdx.x] : LOD_CULLED;
+            // what k_render has to do for the batch: 0 nothing (culled, or no point to draw), 1 draw, 2 draw with the checked variant
+            const uint32_t kind = !(lod & LOD_CULLED) && (lod & LOD_NPR_MASK) ? ((rec_flags & bf_generic(a.parts)) ? 2u : 1u) : 0u;
+            const uint64_t below = (1ull << threadIdx.x) - 1ull;
+            // (the list entry is the whole record k_render's workgroup starts from, see RenderArgs::order)
+            DrawRec r = {0, 0, 0, 0, 0, 0};
+            if (kind) { r.b = bb; r.lod = lod; r.esc_total = rec_esc_total; r.esc_mid = rec_esc_mid; r.sep_off = rec_sep_off; }
+            // the ordinary list: class after class inside the chunk
+            const uint32_t npr = r.lod & LOD_NPR_MASK;
+            const uint32_t cls = a.work_classes > 1 && npr ? (uint32_t)(WORK_CLASSES - 1) - min((npr - 1u) / (64u / WORK_CLASSES), (uint32_t)(WORK_CLASSES - 1)) : 0u;
+            uint32_t base = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)WORK_CLASSES; ++k) {
-            const uint64_t m = __ballot(kind == 1u && cls == k);
-            if (threadIdx.x == 0) a.chunk_count[k * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
-            if (kind == 1u && cls == k) a.order[block * PREPASS_BATCHES + base + (uint32_t)__popcll(m & below)] = r;
-            base += (uint32_t)__popcll(m);
+            for (uint32_t k = 0; k < (uint32_t)WORK_CLASSES; ++k) {
+                const uint64_t m = __ballot(kind == 1u && cls == k);
+                if (threadIdx.x == 0) a.chunk_count[k * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
+                if (kind == 1u && cls == k) a.order[block * PREPASS_BATCHES + base + (uint32_t)__popcll(m & below)] = r;
+                base += (uint32_t)__popcll(m);
+            }
+            {   // the checked list
+                const uint64_t m = __ballot(kind == 2u);
+                if (threadIdx.x == 0) a.chunk_count[WORK_CLASSES * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
+                if (kind == 2u) a.order[(size_t)a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
+            }
         }
-        {   // the checked list
-            const uint64_t m = __ballot(kind == 2u);
-            if (threadIdx.x == 0) a.chunk_count[WORK_CLASSES * PCR_MAX_PREPASS_WORKGROUPS + block] = (uint32_t)__popcll(m);
-            if (kind == 2u) a.order[(size_t)a.order_stride + block * PREPASS_BATCHES + (uint32_t)__popcll(m & below)] = r;
-        }
+        PCR_PTL(4);
+        return;
     }
     // LDS framebuffer windows of the workgroups that draw
-    // ... and a vote: do (nearly) all of the workgroup's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
+    // ... and a vote: do (nearly) all of the chunk's batches (32 neighbours in the file) lie mostly outside their windows? Only then does
     // k_render pre-read the framebuffer words of such a batch's points (WinPlan::mostly_outside, project_request): a few batches of
     // that kind in a frame are cheaper unfiltered, a frame full of them (an unsorted stream) is not.
     __shared__ uint32_t s_vote[2];                          // plans drawn, of those mostly outside
     if (threadIdx.x < 2) s_vote[threadIdx.x] = 0;
-    __syncthreads();
+    __syncthreads();                                        // (s_lod is complete)
+    PCR_PTL(5);
     bool mine_drawn = false, mine_outside = false;
     if (plan_lane) {
         const uint32_t lod = s_lod[slot];
@@ -423,12 +445,22 @@ __device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t 
             }
         }
     }
+    PCR_PTL(6);
     __syncthreads();
+    PCR_PTL(7);
     // (the plan was written with the batch's own verdict; the neighbourhood's vote takes it back)
     if (mine_drawn && mine_outside && s_vote[1] * PCR_VOTE_DEN < s_vote[0] * PCR_VOTE_NUM) {
         a.win[pb * parts + part].mostly_outside = 0;
         if (a.win_hqs) a.win_hqs[pb * parts + part].mostly_outside = 0;
     }
+}
+
+// Workgroup w of a launch's prepass part: chunk w / 2, the lists (even) or the plans (odd)
+constexpr uint32_t PREPASS_WGS_PER_CHUNK = 2;
+__device__ __forceinline__ void lod_prepass_block(const RenderArgs &a, uint32_t w)
+{
+    if (w & 1u) lod_prepass_chunk<false>(a, w >> 1);
+    else        lod_prepass_chunk<true>(a, w >> 1);
 }
 
 // One lane per run: the screen rectangle of the run's bounding box (k_bounds), then LDS pixels for the RUNS rectangles. Only a
@@ -507,8 +539,9 @@ __device__ __forceinline__ IRect group_box_rect(const pcr_render_params &p, cons
         const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
         const float w = dot4(p.transform + 12, x, y, z, 1.0f);
         front = front && w > 1.0e-6f;
-        const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
-        const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
+        const float rw = __builtin_amdgcn_rcpf(w);              // (a placement hint: v_rcp_f32's 1 ulp is plenty, an IEEE division is ten instructions)
+        const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) * rw * 0.5f + 0.5f) * fw;
+        const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) * rw * 0.5f + 0.5f) * fh;
         minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
     }
 #pragma unroll
@@ -538,8 +571,20 @@ __device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int
     const float fw = (float)p.width, fh = (float)p.height;
     const float bmin[3] = { in.box[0], in.box[1], in.box[2] }, bmax[3] = { in.box[3], in.box[4], in.box[5] };
     const IRect none = { 0x3FFFFFFF, 0x3FFFFFFF, -1, -1 };      // identity of the union
+    // the batch's own bounding box (GPUBatch: it holds every point but the garbage tails of SURVEY B.4): the dirty tiles are marked under it
+    const IRect whole = group_box_rect(p, in.gmin, in.gmax, r);
+    // ... and what k_bounds saw of the workgroup's own chains, garbage tails included (a hint: float dequantisation): the one
+    // window of the workgroup if the LDS holds it
+    IRect single = group_box_rect(p, in.all, in.all + 3, r);
+    if (rect_area(whole) > 0) single = rect_area(single) > 0 ? rect_intersect(single, whole) : whole;
+    const int cap = window_capacity(in.esc_count, a.win_pixel_bytes, a.dyn_lds_bytes, a.parts);
+    const int cap_hqs = a.win_hqs ? window_capacity(in.esc_count, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes, a.parts) : cap;
+    // The rectangle of MY run of chains -- eight corners per lane, two thirds of this function's arithmetic, and the prepass block sits
+    // on every frame's critical path (it was 6 of the 12 us of the frame turn) -- is worked out only if some plan of the group needs
+    // windows per run: 96 % of the half-batches of the benchmark frame get the one window.
     IRect mine = none;
-    {
+    const bool single_fits = rect_area(single) > 0 && rect_area(single) <= min(cap, cap_hqs);
+    if (!single_fits) {
         bool front = true;
         float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
 #pragma unroll
@@ -547,8 +592,9 @@ __device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int
             const float x = (c & 1) ? bmax[0] : bmin[0], y = (c & 2) ? bmax[1] : bmin[1], z = (c & 4) ? bmax[2] : bmin[2];
             const float w = dot4(p.transform + 12, x, y, z, 1.0f);
             front = front && w > 1.0e-6f;
-            const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fw;
-            const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) / w * 0.5f + 0.5f) * fh;
+            const float rw = __builtin_amdgcn_rcpf(w);
+            const float sx = (dot4(p.transform + 0, x, y, z, 1.0f) * rw * 0.5f + 0.5f) * fw;
+            const float sy = (dot4(p.transform + 4, x, y, z, 1.0f) * rw * 0.5f + 0.5f) * fh;
             minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
         }
         // (a box that reaches behind the camera, holds a NaN, or lies off screen gets no rectangle: its points take the global path)
@@ -557,23 +603,15 @@ __device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int
             mine.y0 = max(0, (int)floorf(fmaxf(miny, -2.0f)) - 1); mine.y1 = min(p.height - 1, (int)floorf(fminf(maxy, fh + 2.0f)) + 1);
             if (mine.x1 < mine.x0 || mine.y1 < mine.y0) mine = none;
         }
-    }
-    // the batch's own bounding box (GPUBatch: it holds every point but the garbage tails of SURVEY B.4): the dirty tiles are marked under it
-    const IRect whole = group_box_rect(p, in.gmin, in.gmax, r);
-    // ... and what k_bounds saw of the workgroup's own chains, garbage tails included (a hint: float dequantisation): the one
-    // window of the workgroup if the LDS holds it
-    IRect single = group_box_rect(p, in.all, in.all + 3, r);
-    if (rect_area(whole) > 0) {
         // No window reaches outside the rectangle the dirty tiles are marked under (FrameView::tiles): a point INSIDE its window is
         // never tested against that rectangle, so a window sticking out of it -- a run's box holds its chains' garbage tails -- would
         // let the merge write framebuffer words in a tile nobody marked. What lies outside goes the off-window way,
-        // which marks.
-        single = rect_area(single) > 0 ? rect_intersect(single, whole) : whole;
-        mine = rect_intersect(mine, whole);
+        // which marks. (`single` is cut to it above.)
+        if (rect_area(whole) > 0) mine = rect_intersect(mine, whole);
     }
-    const bool outside = assign_windows(window_capacity(in.esc_count, a.win_pixel_bytes, a.dyn_lds_bytes, a.parts), mine, single, in.cut, r, a.win + b * a.parts + part);
+    const bool outside = assign_windows(cap, mine, single, in.cut, r, a.win + b * a.parts + part);
     if (a.win_hqs)                                              // (uniform) the colour pass of the same frame: 20-byte pixels
-        assign_windows(window_capacity(in.esc_count, WIN_PIXEL_BYTES_HQS, a.dyn_lds_bytes, a.parts), mine, single, in.cut, r, a.win_hqs + b * a.parts + part);
+        assign_windows(cap_hqs, mine, single, in.cut, r, a.win_hqs + b * a.parts + part);
     // dirty tiles (FrameView::tiles): everything under the batch's rectangle; a batch without one can write anywhere
     uint32_t wxy = 0, wwh = 0;
     if (a.f.tiles) {
@@ -606,7 +644,8 @@ __device__ __forceinline__ bool plan_windows(const RenderArgs &a, int64_t b, int
 
 __global__ void __launch_bounds__(PREPASS_THREADS) k_lod_prepass(RenderArgs a) { lod_prepass_block(a, blockIdx.x); }
 
-__device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st)
+// publish: write lod[b] and count the batch in the statistics (the lists' workgroup; the plans' workgroup only wants the decision)
+__device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64_t b, int lane, pcr_render_stats &st, bool publish)
 {
     const uint32_t group_shift = (threadIdx.x & 63u) & ~(uint32_t)(PREPASS_LANES - 1);   // my group's bits in a wave ballot
     const pcr_gpu_batch g = a.s.batches[b];
@@ -615,7 +654,7 @@ __device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64
     const float bmin[3] = { g.min_x - lm[0], g.min_y - lm[1], g.min_z - lm[2] };             // :340
     const float bmax[3] = { g.max_x - lm[0], g.max_y - lm[1], g.max_z - lm[2] };             // :341
 
-    if (lane == 0) st.batches_total = 1;
+    if (lane == 0 && publish) st.batches_total = 1;
     if (p.enable_frustum_culling) {                                                          // :342-344
         // planes (3-0), (3+0), (3+1), (3-1), (3-2), (3+2) of the transposed matrix (three.js convention, :246-259);
         // x + s*y with s = +-1 is the same rounding as x +- y
@@ -628,7 +667,7 @@ __device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64
                                    M[15] + sgn * M[4 * r + 3], bmin, bmax);
         const uint32_t votes = (uint32_t)(__ballot(accept) >> group_shift) & 0xFFu;
         if (votes != 0xFFu) {
-            if (lane == 0) { a.lod[b] = LOD_CULLED; st.batches_culled = 1; }      // (plain stores to distinct fields: with `+=` hipcc
+            if (lane == 0 && publish) { a.lod[b] = LOD_CULLED; st.batches_culled = 1; }      // (plain stores to distinct fields: with `+=` hipcc
                                                                                       // merged them into one store at a computed offset -- scratch)
             return LOD_CULLED;
         }
@@ -658,7 +697,7 @@ __device__ __forceinline__ uint32_t lod_prepass_batch(const RenderArgs &a, int64
     npr = min(npr, p.points_per_thread);
     npr = max(npr, 0);
     const uint32_t lod = (uint32_t)npr | (use_double ? LOD_DOUBLE : 0u);
-    if (lane == 0) {
+    if (lane == 0 && publish) {
         a.lod[b] = lod;
         st.points_iterated = (int64_t)npr * PCR_WORKGROUP_SIZE;
         st.batches_double = use_double ? 1 : 0;
@@ -1114,7 +1153,7 @@ __global__ void __launch_bounds__(PCR_WORKGROUP_SIZE) k_bounds(StreamView s, con
 }
 
 #ifdef PCR_EXP_TIMELINE   /* experiment: per-workgroup time stamps of k_render's phases (100 MHz wall clock) + the hardware slot it ran on */
-__device__ unsigned long long g_timeline[8192 * 8];
+__device__ unsigned long long g_timeline[8192 * 8];         // (rows 7000..: the prepass blocks' stamps, PCR_PTL)
 __device__ unsigned long long g_wave_end[8192 * 16];        // per wave: wall clock at the end of its point loop
 #define PCR_TL(slot) do { if (threadIdx.x == 0) g_timeline[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
 #else
@@ -2067,7 +2106,7 @@ __global__ void __launch_bounds__(PREPASS_THREADS) k_las_prepass(LasArgs a)
         las_prepass_batch(a, b, st, &heavy);
         if (a.level[b] >= 0 && b != a.s.num_batches - 1) cls = heavy ? 0u : 1u;      // render.cu:153-155, :201-202
     }
-    commit_stats(st, a.stats);
+    commit_stats(st, a.stats, blockIdx.x);
     // compaction of the batches to draw, order preserving inside a class: a ballot per wave and class, the waves' counts through LDS
     __shared__ uint32_t s_wave_count[LAS_CLASSES][PREPASS_THREADS / 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
