@@ -5,12 +5,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pcrhpg24_amd as P
 from pcrhpg24_amd import _native as N
-ap = argparse.ArgumentParser(); ap.add_argument("--batches", type=int, default=0); ap.add_argument("--out", default=""); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cull", type=int, default=0); ap.add_argument("--lod", type=int, default=100)
+ap = argparse.ArgumentParser(); ap.add_argument("--batches", type=int, default=0); ap.add_argument("--out", default=""); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cull", type=int, default=0); ap.add_argument("--lod", type=int, default=100); ap.add_argument("--layout", type=int, default=-1, help="pcr_set_stream_layout value (4: the point-keys patch)")
 args = ap.parse_args()
 image, _ = P.synth_encode(100_000_000, 0x5EED, nthreads=16)
 hf = P.HuffmanFile(image)
 nb = args.batches or hf.numBatches
 ctx = P.Context(0); ctx.set_image_size(args.width, args.height)
+if args.layout >= 0:
+    ctx.set_stream_layout(args.layout)
 ctx.stream_begin(hf.header(0, nb), 0)
 for b0 in range(0, nb, 100):
     ctx.upload_batches(b0, [hf.blob(b) for b in range(b0, min(b0 + 100, nb))])
