@@ -76,3 +76,20 @@ ss = us[:, 0] > 60
 print("steady state (start > 60 us): n=%d, sorted durations:" % ss.sum(), np.round(srt[ss].mean(axis=0), 1))
 if args.out:
     np.save(args.out, t)
+# the slowest workgroups: which batches are they, when did they start? (LOD 100 %, no culling: list entry == batch)
+idx = np.nonzero(live)[0]
+loopd = us[:, 3] - us[:, 2]
+print("slowest workgroups (loop us, lifetime us, start us, end us, batch, part):")
+for j in np.argsort(-loopd)[:24]:
+    x = int(idx[j])
+    if parts == 2:
+        part, entry = (x >> 3) & 1, (x >> 4) * 8 + (x & 7)
+    else:
+        part, entry = 0, x
+    print("  %7.1f %7.1f %7.1f %7.1f  %5d %d" % (loopd[j], life[j], us[j, 0], us[j, 5], entry, part))
+late = np.argsort(-us[:, 5])[:24]
+print("last workgroups to end (end us, start us, loop us, batch, part):")
+for j in late:
+    x = int(idx[j])
+    part, entry = ((x >> 3) & 1, (x >> 4) * 8 + (x & 7)) if parts == 2 else (0, x)
+    print("  %7.1f %7.1f %7.1f  %5d %d" % (us[j, 5], us[j, 0], loopd[j], entry, part))
