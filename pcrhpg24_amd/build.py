@@ -20,7 +20,9 @@ HIP_LIB = os.environ.get("PCR_HIP_LIB") or os.path.join(PKG_DIR, "libpcr_hip.so"
 HOST_LIB = os.path.join(PKG_DIR, "libpcr_host.so")
 
 # -ffp-contract=off is part of the numeric contract: FMAs are spelled out in the sources.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -amdgpu-sched-strategy=max-ilp: hipcc's scheduler that orders a region for instruction-level parallelism first. Same-box A/B of the
+# whole library (profiles/r04_experiments.md section 10): the HQS frame -3 %, every other row within +-1 %.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-Wextra", "-ffp-contract=off", "-fPIC", "-shared"]
 
 

@@ -529,7 +529,7 @@ const char *pcr_last_error(const pcr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Bumped with every change to k_render / k_transcode that can move a measured number: what a stored profile (HBM traffic
 // from PMC counters, profiles/pmc_traffic_latest.json) was measured on is compared with this before it is quoted.
-const char *pcr_kernel_version(void) { return "r04.v110"; }
+const char *pcr_kernel_version(void) { return "r04.v111"; }
 
 int pcr_create(int device, pcr_ctx **out)
 {
