@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-opcode census of the point loop of a k_render instantiation, from the gfx950 assembly hipcc writes with --save-temps.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I include -I pcrhpg24_amd/csrc --save-temps \
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -fPIC -shared -I include -I pcrhpg24_amd/csrc --save-temps \
           pcrhpg24_amd/csrc/pcr_api.hip -o /tmp/isa/lib.so          (in an empty directory: the .s lands in the cwd)
     python tools/isa_census.py /tmp/isa/pcr_api-hip-amdgcn-amd-amdhsa-gfx950.s [mangled kernel name] > profiles/rNN_isa_census.md
 
